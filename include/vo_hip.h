@@ -1,0 +1,100 @@
+/*
+ * libvo_hip -- C-ABI of the MI355X (gfx950) data-parallel front end of the
+ * visual-odometry pipeline.  Every entry point is `extern "C"`, takes plain
+ * pointers and sizes, returns 0 on success or a negative VO_E* code, and never
+ * throws; vo_last_error() holds the message of the calling thread's last failure.
+ *
+ * The reference (pure Python) has no FFI; the boundary these functions replace is
+ * the cv2/scipy call made inside each vo_pipeline method.  Each declaration cites
+ * the reference call site it stands in for (paths relative to the reference root).
+ *
+ * Memory: the caller owns every input and output buffer.  `mem` says where they
+ * live: VO_MEM_HOST (the library stages through its own device buffers and
+ * synchronises before returning) or VO_MEM_DEVICE (raw device pointers, e.g.
+ * torch tensor.data_ptr(); the call is asynchronous on the context's stream).
+ * A context is bound to one GPU and one HIP stream and is not re-entrant.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK 0
+#define VO_EINVAL (-1)   /* bad argument (shape, null pointer, range) */
+#define VO_EHIP (-2)     /* a HIP runtime call failed */
+#define VO_ENOMEM (-3)   /* allocation failed */
+#define VO_ESTATE (-4)   /* object used in the wrong state */
+
+#define VO_MEM_HOST 0
+#define VO_MEM_DEVICE 1
+
+typedef struct vo_ctx vo_ctx;
+typedef struct vo_pyr vo_pyr;
+
+/* ---- context ------------------------------------------------------------ */
+const char *vo_last_error(void);
+int vo_version(void);
+/* stream: a hipStream_t (may be NULL = the device's default stream). */
+int vo_ctx_create(int device, void *stream, vo_ctx **out);
+int vo_ctx_destroy(vo_ctx *ctx);
+int vo_sync(vo_ctx *ctx);
+/* Timing helpers (HIP events on the context's stream). */
+int vo_timer_start(vo_ctx *ctx);
+int vo_timer_stop_ms(vo_ctx *ctx, float *ms);  /* records stop, synchronises, returns elapsed */
+
+/* ---- image pyramid ------------------------------------------------------
+ * Replaces the pyramid that cv.calcOpticalFlowPyrLK builds internally for both
+ * images on every call (vo_pipeline/poseEstimation.py:122-132): Gaussian 5-tap
+ * pyrDown, REFLECT_101, level count clamped so every level is larger than `win`.
+ * A vo_pyr holds `batch` images of one size; level 0 aliases the caller's device
+ * buffer (VO_MEM_DEVICE: it must stay valid while the pyramid is in use) or a
+ * library-owned copy (VO_MEM_HOST).
+ */
+int vo_pyr_create(vo_ctx *ctx, int batch, int height, int width, int max_level, int win, vo_pyr **out);
+int vo_pyr_destroy(vo_pyr *pyr);
+int vo_pyr_max_level(const vo_pyr *pyr);  /* effective last level (0-based) */
+int vo_pyr_level_shape(const vo_pyr *pyr, int level, int *height, int *width, int64_t *pitch);
+/* img: batch images, row stride `row_stride` bytes, image stride `img_stride` bytes. */
+int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem);
+/* Copy one level of one image to a tight host buffer (tests / debugging). */
+int vo_pyr_download(vo_ctx *ctx, const vo_pyr *pyr, int image, int level, uint8_t *host_out);
+
+/* ---- pyramidal Lucas-Kanade ---------------------------------------------
+ * Replaces cv.calcOpticalFlowPyrLK(img0, img1, float32(prev_kpts), None,
+ * winSize, maxLevel, criteria=(COUNT|EPS, iters, eps), flags=
+ * OPTFLOW_LK_GET_MIN_EIGENVALS, minEigThreshold) -- PoseEstimation.KLT,
+ * vo_pipeline/poseEstimation.py:116-133; caller vo_pipeline/continuousVO.py:167.
+ * prev/next: pyramids of the same geometry.  Points are (batch, n, 2) float32
+ * (x, y); image b of `prev` is tracked into image b of `next`.
+ * init_pts may be NULL (start at prev_pts, as the reference does).
+ * status: (batch, n) uint8, 1 = tracked.  err: (batch, n) float32 min-eigenvalue,
+ * may be NULL.
+ */
+typedef struct vo_klt_params {
+    int max_iters;     /* criteria count (clamped to [0,100]) */
+    float eps;         /* criteria epsilon (clamped to [0,10], squared internally) */
+    float min_eig;     /* minEigThreshold */
+} vo_klt_params;
+
+int vo_klt_track(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
+                 const float *prev_pts, const float *init_pts, int n,
+                 const vo_klt_params *params,
+                 float *next_pts, uint8_t *status, float *err, int mem);
+
+/* Forward + backward track and the bidirectional test the reference's
+ * TrackPoints.trackKLT intends (vo_pipeline/trackPoints.py:19-64, 154-161):
+ * accept when |p - back(fwd(p))| < lambda in both axes.  mask: (batch, n) uint8.
+ * next_pts holds the forward result for accepted points and (0,0) otherwise. */
+int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
+                    const float *prev_pts, int n, const vo_klt_params *params,
+                    float lambda, float *next_pts, uint8_t *mask, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from visual_odometry_amd import hip
+    return hip.Context(0)

@@ -1,0 +1,75 @@
+"""ctypes binding of csrc/libvo_hip.so (C-ABI declared in include/vo_hip.h)."""
+import ctypes
+import os
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "csrc", "libvo_hip.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_vp = ctypes.c_void_p
+
+VO_MEM_HOST = 0
+VO_MEM_DEVICE = 1
+
+
+class KltParams(ctypes.Structure):
+    _fields_ = [("max_iters", ctypes.c_int), ("eps", ctypes.c_float), ("min_eig", ctypes.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/vo_hip.h declares
+SIGNATURES = {
+    "vo_last_error": (ctypes.c_char_p, []),
+    "vo_version": (ctypes.c_int, []),
+    "vo_ctx_create": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "vo_ctx_destroy": (ctypes.c_int, [c_vp]),
+    "vo_sync": (ctypes.c_int, [c_vp]),
+    "vo_timer_start": (ctypes.c_int, [c_vp]),
+    "vo_timer_stop_ms": (ctypes.c_int, [c_vp, c_f32p]),
+    "vo_pyr_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(c_vp)]),
+    "vo_pyr_destroy": (ctypes.c_int, [c_vp]),
+    "vo_pyr_max_level": (ctypes.c_int, [c_vp]),
+    "vo_pyr_level_shape": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "vo_pyr_build": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "vo_pyr_download": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp]),
+    "vo_klt_track": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.POINTER(KltParams),
+                                    c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_klt_track_fb": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.POINTER(KltParams),
+                                       ctypes.c_float, c_vp, c_vp, ctypes.c_int]),
+}
+
+_lib = None
+
+
+class VoError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvo_hip.so.  Raises if the library is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VoError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                      "(or __graft_entry__.build()); the HIP library is required, there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vo_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise VoError(f"{what}: [{rc}] {msg}")

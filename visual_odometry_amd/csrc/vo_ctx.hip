@@ -1,0 +1,99 @@
+// Context, error reporting, staging buffers and stream timers of libvo_hip.
+#include "vo_internal.h"
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void vo_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *vo_last_error(void) { return g_err; }
+extern "C" int vo_version(void) { return 100; }
+
+extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
+{
+    VO_REQUIRE(out != nullptr, "vo_ctx_create: out is NULL");
+    int count = 0;
+    VO_HIP_CHECK(hipGetDeviceCount(&count));
+    VO_REQUIRE(device >= 0 && device < count, "vo_ctx_create: device %d out of range (%d visible)", device, count);
+    VO_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        vo_set_error("vo_ctx_create: device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
+        return VO_ESTATE;
+    }
+    vo_ctx *c = new (std::nothrow) vo_ctx();
+    if (!c) { vo_set_error("vo_ctx_create: out of host memory"); return VO_ENOMEM; }
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    VO_HIP_CHECK(hipEventCreate(&c->ev0));
+    VO_HIP_CHECK(hipEventCreate(&c->ev1));
+    *out = c;
+    return VO_OK;
+}
+
+extern "C" int vo_ctx_destroy(vo_ctx *ctx)
+{
+    if (!ctx) return VO_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->stage)
+        if (b.ptr) hipFree(b.ptr);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return VO_OK;
+}
+
+extern "C" int vo_sync(vo_ctx *ctx)
+{
+    VO_REQUIRE(ctx != nullptr, "vo_sync: ctx is NULL");
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_timer_start(vo_ctx *ctx)
+{
+    VO_REQUIRE(ctx != nullptr, "vo_timer_start: ctx is NULL");
+    VO_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_timer_stop_ms(vo_ctx *ctx, float *ms)
+{
+    VO_REQUIRE(ctx != nullptr && ms != nullptr, "vo_timer_stop_ms: NULL argument");
+    VO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    VO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    VO_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VO_OK;
+}
+
+int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    vo_devbuf &b = ctx->stage[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.ptr) {
+            // a previous asynchronous call may still read the old buffer
+            VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            VO_HIP_CHECK(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        size_t cap = bytes + bytes / 2;
+        hipError_t e = hipMalloc(&b.ptr, cap);
+        if (e != hipSuccess) {
+            vo_set_error("device allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
+            return VO_ENOMEM;
+        }
+        b.cap = cap;
+    }
+    *out = b.ptr;
+    return VO_OK;
+}

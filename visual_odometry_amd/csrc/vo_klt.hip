@@ -1,0 +1,474 @@
+// Pyramidal Lucas-Kanade tracker, one keypoint per 64-lane wavefront.
+//
+// Semantics: cv.calcOpticalFlowPyrLK as the reference calls it
+// (vo_pipeline/poseEstimation.py:116-133): translation model, 21x21 window,
+// 14-bit fixed-point bilinear weights, int16 Scharr derivatives (x32 gain),
+// float32 2x2 normal equations, min-eigenvalue test, <= max_iters Gauss-Newton
+// steps per level with the epsilon and oscillation stops.
+//
+// Mapping: lane l < 63 owns window column l % 21 and the 7 rows 7*(l / 21)...;
+// its template values (I, Ix, Iy) stay in registers for the whole level.
+// Per wave the kernel stages in LDS
+//   * the 24x24 previous-image tile (as 16-bit pixel pairs {p[x], p[x+1]} ready
+//     for v_dot2_u32_u16 against the packed bilinear weights),
+//   * the 22x22 Scharr tile computed from it, and
+//   * a (22+2M)x(21+2M) tile of the next image around the current estimate,
+//     re-staged only when the estimate leaves the M-pixel margin.
+// Row strides are chosen so that the three 7-row strips of a half-wave hit
+// disjoint LDS banks.  The 2x2 system and the right-hand side are reduced over
+// the wave with DPP adds; every branch is wave-uniform.
+#include "vo_internal.h"
+
+#define KLT_WIN 21
+#define KLT_HALF 10.0f
+#define KLT_M 4                         // margin of the next-image tile (pixels)
+#define JT_S 35                         // next-image tile row stride (dwords), 7*35 % 32 == 21
+#define JT_ROWS (KLT_WIN + 1 + 2 * KLT_M)
+#define JT_COLS (KLT_WIN + 2 * KLT_M)   // pair columns
+#define PT_S 26                         // previous-image pair tile stride (dwords)
+#define PT_ROWS 24
+#define DT_S 26                         // derivative tile stride (dwords)
+#define DT_ROWS 22
+#define LDS_A_DWORDS (JT_S * JT_ROWS)   // region A: previous tile, later next-image tile
+#define LDS_B_DWORDS (DT_S * DT_ROWS)   // region B: derivative tile
+#define LDS_WAVE_DWORDS (((LDS_A_DWORDS + LDS_B_DWORDS) + 3) / 4 * 4)
+#define KLT_WAVES 4
+
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+
+struct KltLevel {
+    const uint8_t *prev;
+    const uint8_t *next;
+    int w, h;
+    int64_t ppitch, pstride;  // previous image: row pitch, image stride
+    int64_t npitch, nstride;  // next image
+};
+
+struct KltArgs {
+    KltLevel lv[VO_MAX_LEVELS];
+    int max_level;
+    int n;      // keypoints per image
+    int batch;  // images
+    int blocks_per_image;
+    const float *prev_pts;
+    const float *init_pts;
+    float *next_pts;
+    uint8_t *status;
+    float *err;
+    int max_iters;
+    double eps2;
+    float min_eig;
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wave execute in order; this only stops the compiler
+    // from moving LDS accesses across the hand-over point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// Sum over the 64 lanes, returned in every lane (fixed order => deterministic).
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+    v += dpp_f<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+    v += dpp_f<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ int refl(int i, int n)
+{
+    // BORDER_REFLECT_101 for one fold on either side; positions further out are
+    // only touched by tile margins that no valid window reads, so they are clamped.
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), c, false);
+}
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b), c, false);
+}
+
+// Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
+// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.
+template <int ROWS, int PAIRS, int STRIDE>
+__device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
+                                            int x0, int y0, int lane)
+{
+    constexpr int GROUPS = (PAIRS + 2) / 3;  // 3 pairs from one 4-byte read
+    const bool inside = (x0 >= 0) && (y0 >= 0) && (x0 + 3 * GROUPS + 1 <= w) && (y0 + ROWS <= h);
+    if (inside) {
+        const uint8_t *base = img + (int64_t)y0 * pitch + x0;
+        for (int idx = lane; idx < ROWS * GROUPS; idx += 64) {
+            int r = idx / GROUPS, g = idx - r * GROUPS;
+            uint32_t q;
+            __builtin_memcpy(&q, base + (int64_t)r * pitch + 3 * g, 4);
+            uint32_t p0 = q & 0xff, p1 = (q >> 8) & 0xff, p2 = (q >> 16) & 0xff, p3 = q >> 24;
+            uint32_t *d = lds + r * STRIDE + 3 * g;
+            d[0] = p0 | (p1 << 16);
+            if (3 * g + 1 < STRIDE) d[1] = p1 | (p2 << 16);
+            if (3 * g + 2 < STRIDE) d[2] = p2 | (p3 << 16);
+        }
+    } else {
+        for (int idx = lane; idx < ROWS * PAIRS; idx += 64) {
+            int r = idx / PAIRS, c = idx - r * PAIRS;
+            int y = refl(y0 + r, h);
+            int xa = refl(x0 + c, w), xb = refl(x0 + c + 1, w);
+            const uint8_t *row = img + (int64_t)y * pitch;
+            lds[r * STRIDE + c] = (uint32_t)row[xa] | ((uint32_t)row[xb] << 16);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[KLT_WAVES * LDS_WAVE_DWORDS];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = uniform(threadIdx.x >> 6);
+
+    // blocks b and b+8 share an XCD (round-robin dispatch): keep one image's
+    // keypoints on one XCD so its pyramid stays in that XCD's L2.
+    int bid = blockIdx.x, img, kb;
+    if ((A.batch & 7) == 0) {
+        int xcd = bid & 7, j = bid >> 3;
+        img = (j / A.blocks_per_image) * 8 + xcd;
+        kb = j % A.blocks_per_image;
+    } else {
+        img = bid / A.blocks_per_image;
+        kb = bid % A.blocks_per_image;
+    }
+    const int kp = kb * KLT_WAVES + wid;
+    if (kp >= A.n) return;
+    const int64_t pidx = (int64_t)img * A.n + kp;
+
+    uint32_t *ldsA = lds_all + wid * LDS_WAVE_DWORDS;
+    uint32_t *ldsB = ldsA + LDS_A_DWORDS;
+
+    // lane -> window column and 7-row strip; lane 63 shadows lane 0 with zero weight
+    const bool active = lane < 63;
+    const int wl = active ? lane : 0;
+    const int col = wl % KLT_WIN;
+    const int row0 = (wl / KLT_WIN) * 7;
+
+    const float px0 = A.prev_pts[2 * pidx], py0 = A.prev_pts[2 * pidx + 1];
+    float outx = 0.f, outy = 0.f;
+    int status = 1;
+    float errv = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    for (int level = A.max_level; level >= 0; --level) {
+        const KltLevel L = A.lv[level];
+        const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
+        const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
+        const float sc = (float)(1. / (1 << level));
+        float px = px0 * sc, py = py0 * sc;
+        float nx, ny;
+        if (level == A.max_level) {
+            if (A.init_pts) { nx = A.init_pts[2 * pidx] * sc; ny = A.init_pts[2 * pidx + 1] * sc; }
+            else { nx = px; ny = py; }
+        } else {
+            nx = outx * 2.f; ny = outy * 2.f;
+        }
+        outx = nx; outy = ny;
+
+        px -= KLT_HALF; py -= KLT_HALF;
+        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
+        if (ipx < -KLT_WIN || ipx >= L.w || ipy < -KLT_WIN || ipy >= L.h) {
+            if (level == 0) { status = 0; errv = 0.f; }
+            continue;
+        }
+        float a = px - (float)ipx, b = py - (float)ipy;
+        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+        int iw01 = __float2int_rn(a * (1.f - b) * 16384.f);
+        int iw10 = __float2int_rn((1.f - a) * b * 16384.f);
+        int iw11 = 16384 - iw00 - iw01 - iw10;
+        uint32_t wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
+        uint32_t wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
+
+        // ---- template: previous-image tile, Scharr tile, bilinear samples ----
+        wave_sync();  // region A may still be read as the coarser level's next-image tile
+        stage_pairs<PT_ROWS, 23, PT_S>(ldsA, pimg, L.ppitch, L.w, L.h, ipx - 1, ipy - 1, lane);
+        wave_sync();
+        for (int idx = lane; idx < DT_ROWS * 22; idx += 64) {
+            int y = idx / 22, x = idx - y * 22;
+            const uint32_t *t = ldsA + y * PT_S + x;
+            uint32_t q00 = t[0], q01 = t[1];
+            uint32_t q10 = t[PT_S], q11 = t[PT_S + 1];
+            uint32_t q20 = t[2 * PT_S], q21 = t[2 * PT_S + 1];
+            int a0 = q00 & 0xffff, a1 = q00 >> 16, a2 = q01 >> 16;
+            int b0 = q10 & 0xffff, b2 = q11 >> 16;
+            int c0 = q20 & 0xffff, c1 = q20 >> 16, c2 = q21 >> 16;
+            int dx = 3 * (a2 - a0) + 10 * (b2 - b0) + 3 * (c2 - c0);
+            int dy = 3 * (c0 - a0) + 10 * (c1 - a1) + 3 * (c2 - a2);
+            // the derivative image is zero outside the image
+            int gx = ipx + x, gy = ipy + y;
+            bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
+            ldsB[y * DT_S + x] = in ? (((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) : 0u;
+        }
+        wave_sync();
+
+        float Iv[7], Ixv[7], Iyv[7];
+        float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
+        {
+            const uint32_t *pt = ldsA + (row0 + 1) * PT_S + col + 1;
+            const uint32_t *dt = ldsB + row0 * DT_S + col;
+            uint32_t pr[8], dxp[8], dyp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pr[k] = pt[k * PT_S];
+                uint32_t d0 = dt[k * DT_S], d1 = dt[k * DT_S + 1];
+                dxp[k] = (d0 & 0xffffu) | (d1 << 16);
+                dyp[k] = (d0 >> 16) | (d1 & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                int ival = (int)(udot2(pr[k], wt, udot2(pr[k + 1], wb, 1u << 8)) >> 9);
+                int ixval = sdot2(dxp[k], wt, sdot2(dxp[k + 1], wb, 1 << 13)) >> 14;
+                int iyval = sdot2(dyp[k], wt, sdot2(dyp[k + 1], wb, 1 << 13)) >> 14;
+                Iv[k] = (float)ival;
+                Ixv[k] = active ? (float)ixval : 0.f;
+                Iyv[k] = active ? (float)iyval : 0.f;
+                sA11 += Ixv[k] * Ixv[k];
+                sA12 += Ixv[k] * Iyv[k];
+                sA22 += Iyv[k] * Iyv[k];
+            }
+        }
+        const float A11 = wave_sum(sA11) * FLT_SCALE;
+        const float A12 = wave_sum(sA12) * FLT_SCALE;
+        const float A22 = wave_sum(sA22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
+        errv = minEig;
+        if (minEig < A.min_eig || D < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+
+        // ---- Gauss-Newton iterations on the next image ----
+        nx -= KLT_HALF; ny -= KLT_HALF;
+        float pdx = 0.f, pdy = 0.f;
+        int ox = 0, oy = 0;
+        bool have_tile = false;
+        for (int j = 0; j < A.max_iters; ++j) {
+            const int inx = uniform((int)floorf(nx)), iny = uniform((int)floorf(ny));
+            if (inx < -KLT_WIN || inx >= L.w || iny < -KLT_WIN || iny >= L.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            int rx = inx - ox, ry = iny - oy;
+            if (!have_tile || rx < 0 || rx > 2 * KLT_M || ry < 0 || ry > 2 * KLT_M) {
+                ox = inx - KLT_M; oy = iny - KLT_M;
+                rx = KLT_M; ry = KLT_M;
+                wave_sync();
+                stage_pairs<JT_ROWS, JT_COLS, JT_S>(ldsA, nimg, L.npitch, L.w, L.h, ox, oy, lane);
+                wave_sync();
+                have_tile = true;
+            }
+            a = nx - (float)inx; b = ny - (float)iny;
+            iw00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+            iw01 = __float2int_rn(a * (1.f - b) * 16384.f);
+            iw10 = __float2int_rn((1.f - a) * b * 16384.f);
+            iw11 = 16384 - iw00 - iw01 - iw10;
+            wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
+            wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
+
+            const uint32_t *jt = ldsA + (ry + row0) * JT_S + rx + col;
+            uint32_t q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = jt[k * JT_S];
+            float sb1 = 0.f, sb2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                int jv = (int)(udot2(q[k], wt, udot2(q[k + 1], wb, 1u << 8)) >> 9);
+                float diff = (float)jv - Iv[k];
+                sb1 += diff * Ixv[k];
+                sb2 += diff * Iyv[k];
+            }
+            const float b1 = wave_sum(sb1) * FLT_SCALE;
+            const float b2 = wave_sum(sb2) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx; ny += dy;
+            outx = nx + KLT_HALF; outy = ny + KLT_HALF;
+            if ((double)dx * dx + (double)dy * dy <= A.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+    }
+
+    if (lane == 0) {
+        A.next_pts[2 * pidx] = outx;
+        A.next_pts[2 * pidx + 1] = outy;
+        A.status[pidx] = (uint8_t)status;
+        if (A.err) A.err[pidx] = errv;
+    }
+}
+
+static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
+{
+    VO_REQUIRE(prev->built && next->built, "vo_klt_track: pyramids must be built first");
+    VO_REQUIRE(prev->batch == next->batch && prev->h[0] == next->h[0] && prev->w[0] == next->w[0] &&
+                   prev->max_level == next->max_level,
+               "vo_klt_track: pyramids differ in geometry");
+    VO_REQUIRE(prev->win == KLT_WIN && next->win == KLT_WIN, "vo_klt_track: only the 21x21 window is implemented (got %d)", prev->win);
+    a.max_level = prev->max_level;
+    a.batch = prev->batch;
+    for (int l = 0; l <= prev->max_level; ++l) {
+        a.lv[l].prev = prev->lvl[l];
+        a.lv[l].next = next->lvl[l];
+        a.lv[l].w = prev->w[l];
+        a.lv[l].h = prev->h[l];
+        a.lv[l].ppitch = prev->pitch[l];
+        a.lv[l].pstride = prev->img_stride[l];
+        a.lv[l].npitch = next->pitch[l];
+        a.lv[l].nstride = next->img_stride[l];
+        // the reflect helper is valid for one fold only
+        VO_REQUIRE(prev->w[l] > KLT_WIN + 1 && prev->h[l] > KLT_WIN + 1, "vo_klt_track: level %d (%dx%d) too small", l, prev->w[l], prev->h[l]);
+    }
+    return VO_OK;
+}
+
+static int launch_klt(vo_ctx *ctx, KltArgs &a)
+{
+    a.blocks_per_image = (a.n + KLT_WAVES - 1) / KLT_WAVES;
+    int64_t blocks = (int64_t)a.blocks_per_image * a.batch;
+    VO_REQUIRE(blocks < (1ll << 31), "vo_klt_track: too many keypoints (%lld workgroups)", (long long)blocks);
+    hipLaunchKernelGGL(klt_track_kernel, dim3((unsigned)blocks), dim3(64 * KLT_WAVES), 0, ctx->stream, a);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+static void set_params(KltArgs &a, const vo_klt_params *p)
+{
+    int it = p->max_iters;
+    it = it < 0 ? 0 : (it > 100 ? 100 : it);
+    double e = (double)p->eps;
+    e = e < 0 ? 0 : (e > 10 ? 10 : e);
+    a.max_iters = it;
+    a.eps2 = e * e;
+    a.min_eig = p->min_eig;
+}
+
+extern "C" int vo_klt_track(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts,
+                            const float *init_pts, int n, const vo_klt_params *params, float *next_pts,
+                            uint8_t *status, float *err, int mem)
+{
+    VO_REQUIRE(ctx && prev && next && params, "vo_klt_track: NULL argument");
+    VO_REQUIRE(n >= 0, "vo_klt_track: n=%d", n);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_klt_track: bad mem flag %d", mem);
+    if (n == 0) return VO_OK;
+    VO_REQUIRE(prev_pts && next_pts && status, "vo_klt_track: NULL point/status buffer");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    KltArgs a = {};
+    int rc = fill_levels(a, prev, next);
+    if (rc) return rc;
+    set_params(a, params);
+    a.n = n;
+    const size_t cnt = (size_t)n * prev->batch;
+    if (mem == VO_MEM_DEVICE) {
+        a.prev_pts = prev_pts; a.init_pts = init_pts; a.next_pts = next_pts; a.status = status; a.err = err;
+        return launch_klt(ctx, a);
+    }
+    void *d_in, *d_init = nullptr, *d_out, *d_st, *d_err;
+    if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
+    if (init_pts && (rc = vo_stage_reserve(ctx, 1, cnt * 8, &d_init))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 2, cnt * 8, &d_out))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 3, cnt, &d_st))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 4, cnt * 4, &d_err))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(d_in, prev_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (init_pts) VO_HIP_CHECK(hipMemcpyAsync(d_init, init_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    a.prev_pts = (const float *)d_in; a.init_pts = (const float *)d_init; a.next_pts = (float *)d_out;
+    a.status = (uint8_t *)d_st; a.err = (float *)d_err;
+    if ((rc = launch_klt(ctx, a))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(next_pts, d_out, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(status, d_st, cnt, hipMemcpyDeviceToHost, ctx->stream));
+    if (err) VO_HIP_CHECK(hipMemcpyAsync(err, d_err, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// Bidirectional acceptance: |p - back| < lambda in both axes and both passes tracked.
+__global__ void klt_fb_check_kernel(const float *__restrict__ prev_pts, const float *__restrict__ back_pts,
+                                    const uint8_t *__restrict__ st_f, const uint8_t *__restrict__ st_b,
+                                    float lambda, float *__restrict__ fwd_pts, uint8_t *__restrict__ mask, int64_t cnt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    float ex = fabsf(prev_pts[2 * i] - back_pts[2 * i]);
+    float ey = fabsf(prev_pts[2 * i + 1] - back_pts[2 * i + 1]);
+    bool ok = st_f[i] && st_b[i] && ex < lambda && ey < lambda;
+    mask[i] = ok ? 1 : 0;
+    if (!ok) { fwd_pts[2 * i] = 0.f; fwd_pts[2 * i + 1] = 0.f; }
+}
+
+extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, int n,
+                               const vo_klt_params *params, float lambda, float *next_pts, uint8_t *mask, int mem)
+{
+    VO_REQUIRE(ctx && prev && next && params, "vo_klt_track_fb: NULL argument");
+    VO_REQUIRE(n >= 0, "vo_klt_track_fb: n=%d", n);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_klt_track_fb: bad mem flag %d", mem);
+    if (n == 0) return VO_OK;
+    VO_REQUIRE(prev_pts && next_pts && mask, "vo_klt_track_fb: NULL point/mask buffer");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t cnt = (size_t)n * prev->batch;
+    int rc;
+    void *d_in, *d_fwd, *d_back, *d_sf, *d_sb, *d_mask;
+    if ((rc = vo_stage_reserve(ctx, 5, cnt * 8, &d_back))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 6, cnt, &d_sf))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 7, cnt, &d_sb))) return rc;
+    if (mem == VO_MEM_DEVICE) {
+        d_in = const_cast<float *>(prev_pts); d_fwd = next_pts; d_mask = mask;
+    } else {
+        if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
+        if ((rc = vo_stage_reserve(ctx, 2, cnt * 8, &d_fwd))) return rc;
+        if ((rc = vo_stage_reserve(ctx, 3, cnt, &d_mask))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(d_in, prev_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    KltArgs f = {};
+    if ((rc = fill_levels(f, prev, next))) return rc;
+    set_params(f, params);
+    f.n = n;
+    f.prev_pts = (const float *)d_in; f.next_pts = (float *)d_fwd; f.status = (uint8_t *)d_sf;
+    if ((rc = launch_klt(ctx, f))) return rc;
+    KltArgs g = {};
+    if ((rc = fill_levels(g, next, prev))) return rc;
+    set_params(g, params);
+    g.n = n;
+    g.prev_pts = (const float *)d_fwd; g.next_pts = (float *)d_back; g.status = (uint8_t *)d_sb;
+    if ((rc = launch_klt(ctx, g))) return rc;
+    unsigned blocks = (unsigned)((cnt + 255) / 256);
+    hipLaunchKernelGGL(klt_fb_check_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float *)d_in,
+                       (const float *)d_back, (const uint8_t *)d_sf, (const uint8_t *)d_sb, lambda, (float *)d_fwd,
+                       (uint8_t *)d_mask, (int64_t)cnt);
+    VO_HIP_CHECK(hipGetLastError());
+    if (mem == VO_MEM_HOST) {
+        VO_HIP_CHECK(hipMemcpyAsync(next_pts, d_fwd, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(mask, d_mask, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}

@@ -1,0 +1,205 @@
+// Gaussian image pyramid (pyrDown) for batches of 8-bit grayscale images.
+//
+// Semantics follow the pyramid cv.calcOpticalFlowPyrLK builds internally for the
+// reference's KLT call (vo_pipeline/poseEstimation.py:122-132): separable
+// [1 4 6 4 1] filter, BORDER_REFLECT_101, dst = (sum + 128) >> 8, destination
+// size ((w+1)/2, (h+1)/2), and a level count clamped so that every level stays
+// larger than the tracking window.
+//
+// HBM-bound byte work: one workgroup turns a (2*64+3) x (2*16+3) input tile,
+// staged once in LDS, into a 64 x 16 output tile; rows are filtered horizontally
+// into 16-bit sums in LDS, then vertically, and each thread stores four output
+// pixels as one aligned dword (level pitches are multiples of 64 bytes).
+#include "vo_internal.h"
+#include <new>
+
+#define PD_TW 64          // output tile width
+#define PD_TH 16          // output tile height
+#define PD_IW (2 * PD_TW + 3)
+#define PD_IH (2 * PD_TH + 3)
+#define PD_IS 132         // LDS row stride of the input tile (bytes)
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    // valid for -n < i < 2n-1, which the window/halo sizes used here guarantee
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int sw, int sh,
+                                                       int64_t spitch, int64_t sstride,
+                                                       uint8_t *__restrict__ dst, int dw, int dh,
+                                                       int64_t dpitch, int64_t dstride)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[PD_IH * PD_IS];
+    __shared__ __attribute__((aligned(16))) uint16_t hsum[PD_IH * PD_TW];
+
+    const int t = threadIdx.x;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+    const uint8_t *simg = src + (int64_t)blockIdx.z * sstride;
+    uint8_t *dimg = dst + (int64_t)blockIdx.z * dstride;
+    const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2;
+
+    // stage the input tile (consecutive threads read consecutive bytes of a row)
+    for (int idx = t; idx < PD_IH * PD_IW; idx += 256) {
+        int r = idx / PD_IW, c = idx - r * PD_IW;
+        int y = iy0 + r, x = ix0 + c;
+        // positions needed only by outputs outside the image may fall outside the
+        // reflect range; clamp them (their results are never stored)
+        y = min(max(y, -(sh - 1)), 2 * sh - 2);
+        x = min(max(x, -(sw - 1)), 2 * sw - 2);
+        y = sh > 1 ? reflect101(y, sh) : 0;
+        x = sw > 1 ? reflect101(x, sw) : 0;
+        tile[r * PD_IS + c] = simg[(int64_t)y * spitch + x];
+    }
+    __syncthreads();
+
+    // horizontal 5-tap on every staged row
+    for (int idx = t; idx < PD_IH * PD_TW; idx += 256) {
+        int r = idx / PD_TW, ox = idx - r * PD_TW;
+        const uint8_t *p = tile + r * PD_IS + 2 * ox;
+        hsum[idx] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
+    }
+    __syncthreads();
+
+    // vertical 5-tap; thread -> 4 consecutive outputs of one row
+    const int oy = t >> 4, oxg = (t & 15) * 4;
+    const int gy = oy0 + oy, gx = ox0 + oxg;
+    if (gy < dh && gx < dw) {
+        const uint16_t *h0 = hsum + (2 * oy) * PD_TW + oxg;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int v = h0[k] + h0[4 * PD_TW + k] + 4 * (h0[PD_TW + k] + h0[3 * PD_TW + k]) + 6 * h0[2 * PD_TW + k];
+            packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
+        }
+        // bytes past dw land in the row's pitch padding
+        *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch + gx) = packed;
+    }
+}
+
+static int eff_max_level(int w, int h, int max_level, int win)
+{
+    for (int level = 0; level <= max_level; ++level) {
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        if (w <= win || h <= win) return level;
+    }
+    return max_level;
+}
+
+extern "C" int vo_pyr_create(vo_ctx *ctx, int batch, int height, int width, int max_level, int win, vo_pyr **out)
+{
+    VO_REQUIRE(ctx && out, "vo_pyr_create: NULL argument");
+    VO_REQUIRE(batch >= 1 && height >= 1 && width >= 1, "vo_pyr_create: bad shape batch=%d h=%d w=%d", batch, height, width);
+    VO_REQUIRE(max_level >= 0 && win >= 1, "vo_pyr_create: bad max_level=%d win=%d", max_level, win);
+    VO_REQUIRE(height > win && width > win, "vo_pyr_create: image %dx%d must be larger than the window %d", width, height, win);
+    if (max_level > VO_MAX_LEVELS - 1) max_level = VO_MAX_LEVELS - 1;
+    vo_pyr *p = new (std::nothrow) vo_pyr();
+    if (!p) { vo_set_error("vo_pyr_create: out of host memory"); return VO_ENOMEM; }
+    p->ctx = ctx;
+    p->batch = batch;
+    p->win = win;
+    p->max_level = eff_max_level(width, height, max_level, win);
+    p->w[0] = width;
+    p->h[0] = height;
+    size_t total = 0;
+    size_t off[VO_MAX_LEVELS] = {0};
+    for (int l = 1; l <= p->max_level; ++l) {
+        p->w[l] = (p->w[l - 1] + 1) / 2;
+        p->h[l] = (p->h[l - 1] + 1) / 2;
+        p->pitch[l] = ((int64_t)p->w[l] + 63) / 64 * 64;
+        p->img_stride[l] = p->pitch[l] * p->h[l];
+        off[l] = total;
+        total += (size_t)p->img_stride[l] * batch;
+    }
+    total += 256;  // slack: the tracker's 4-byte row reads may run 3 bytes past a row
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc((void **)&p->pool, total);
+    if (e != hipSuccess) {
+        delete p;
+        vo_set_error("vo_pyr_create: device allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
+        return VO_ENOMEM;
+    }
+    for (int l = 1; l <= p->max_level; ++l) p->lvl[l] = p->pool + off[l];
+    *out = p;
+    return VO_OK;
+}
+
+extern "C" int vo_pyr_destroy(vo_pyr *pyr)
+{
+    if (!pyr) return VO_OK;
+    hipSetDevice(pyr->ctx->device);
+    hipStreamSynchronize(pyr->ctx->stream);
+    if (pyr->pool) hipFree(pyr->pool);
+    if (pyr->own0) hipFree(pyr->own0);
+    delete pyr;
+    return VO_OK;
+}
+
+extern "C" int vo_pyr_max_level(const vo_pyr *pyr) { return pyr ? pyr->max_level : VO_EINVAL; }
+
+extern "C" int vo_pyr_level_shape(const vo_pyr *pyr, int level, int *height, int *width, int64_t *pitch)
+{
+    VO_REQUIRE(pyr != nullptr, "vo_pyr_level_shape: pyr is NULL");
+    VO_REQUIRE(level >= 0 && level <= pyr->max_level, "vo_pyr_level_shape: level %d out of [0,%d]", level, pyr->max_level);
+    if (height) *height = pyr->h[level];
+    if (width) *width = pyr->w[level];
+    if (pitch) *pitch = pyr->pitch[level];
+    return VO_OK;
+}
+
+extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem)
+{
+    VO_REQUIRE(ctx && pyr && img, "vo_pyr_build: NULL argument");
+    VO_REQUIRE(pyr->ctx == ctx, "vo_pyr_build: pyramid belongs to another context");
+    VO_REQUIRE(row_stride >= pyr->w[0], "vo_pyr_build: row_stride %lld < width %d", (long long)row_stride, pyr->w[0]);
+    VO_REQUIRE(pyr->batch == 1 || img_stride >= row_stride * pyr->h[0], "vo_pyr_build: img_stride %lld too small", (long long)img_stride);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_pyr_build: bad mem flag %d", mem);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    if (mem == VO_MEM_HOST) {
+        // tight library-owned copy of level 0 (+ slack for 4-byte row reads)
+        size_t need = (size_t)pyr->w[0] * pyr->h[0] * pyr->batch + 256;
+        if (pyr->own0_bytes < need) {
+            if (pyr->own0) { VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); VO_HIP_CHECK(hipFree(pyr->own0)); pyr->own0 = nullptr; }
+            hipError_t e = hipMalloc((void **)&pyr->own0, need);
+            if (e != hipSuccess) { vo_set_error("vo_pyr_build: device allocation of %zu bytes failed", need); return VO_ENOMEM; }
+            pyr->own0_bytes = need;
+        }
+        for (int b = 0; b < pyr->batch; ++b)
+            VO_HIP_CHECK(hipMemcpy2DAsync(pyr->own0 + (size_t)b * pyr->w[0] * pyr->h[0], pyr->w[0],
+                                          img + (size_t)b * img_stride, row_stride, pyr->w[0], pyr->h[0],
+                                          hipMemcpyHostToDevice, ctx->stream));
+        pyr->lvl[0] = pyr->own0;
+        pyr->pitch[0] = pyr->w[0];
+        pyr->img_stride[0] = (int64_t)pyr->w[0] * pyr->h[0];
+    } else {
+        pyr->lvl[0] = const_cast<uint8_t *>(img);
+        pyr->pitch[0] = row_stride;
+        pyr->img_stride[0] = img_stride;
+    }
+    for (int l = 1; l <= pyr->max_level; ++l) {
+        dim3 grid((pyr->w[l] + PD_TW - 1) / PD_TW, (pyr->h[l] + PD_TH - 1) / PD_TH, pyr->batch);
+        VO_REQUIRE(grid.z <= 65535u, "vo_pyr_build: batch %d exceeds the grid limit 65535", pyr->batch);
+        hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, ctx->stream, pyr->lvl[l - 1], pyr->w[l - 1], pyr->h[l - 1],
+                           pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l], pyr->h[l], pyr->pitch[l],
+                           pyr->img_stride[l]);
+    }
+    VO_HIP_CHECK(hipGetLastError());
+    pyr->built = true;
+    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_pyr_download(vo_ctx *ctx, const vo_pyr *pyr, int image, int level, uint8_t *host_out)
+{
+    VO_REQUIRE(ctx && pyr && host_out, "vo_pyr_download: NULL argument");
+    VO_REQUIRE(pyr->built, "vo_pyr_download: pyramid not built");
+    VO_REQUIRE(image >= 0 && image < pyr->batch && level >= 0 && level <= pyr->max_level, "vo_pyr_download: image/level out of range");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    VO_HIP_CHECK(hipMemcpy2DAsync(host_out, pyr->w[level], pyr->lvl[level] + (int64_t)image * pyr->img_stride[level],
+                                  pyr->pitch[level], pyr->w[level], pyr->h[level], hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}

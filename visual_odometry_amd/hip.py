@@ -1,0 +1,189 @@
+"""Object layer over the C-ABI: Context, Pyramid, and the batched operators.
+
+Arrays may be numpy (host memory: the library stages and synchronises) or torch
+tensors on the context's GPU (raw device pointers: asynchronous on the stream).
+torch is used as a buffer provider only.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import KltParams, VO_MEM_DEVICE, VO_MEM_HOST, check
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """One (GPU, HIP stream) pair.  Not re-entrant."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.vo_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)), "vo_ctx_create")
+        self.handle = h
+        self.device = int(device)
+
+    @classmethod
+    def from_torch(cls, device: int = 0) -> "Context":
+        """Context on torch's current stream of `device` (so torch ops and events order with it)."""
+        import torch
+        return cls(device, torch.cuda.current_stream(device).cuda_stream)
+
+    def sync(self) -> None:
+        check(self.lib.vo_sync(self.handle), "vo_sync")
+
+    def timer_start(self) -> None:
+        check(self.lib.vo_timer_start(self.handle), "vo_timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(self.lib.vo_timer_stop_ms(self.handle, ctypes.byref(ms)), "vo_timer_stop_ms")
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.vo_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Pyramid:
+    """Gaussian pyramid of `batch` grayscale uint8 images of one size."""
+
+    def __init__(self, ctx: Context, batch: int, height: int, width: int, max_level: int = 8, win: int = 21):
+        self.ctx = ctx
+        self.batch, self.height, self.width, self.win = int(batch), int(height), int(width), int(win)
+        h = ctypes.c_void_p()
+        check(ctx.lib.vo_pyr_create(ctx.handle, self.batch, self.height, self.width, int(max_level), self.win,
+                                    ctypes.byref(h)), "vo_pyr_create")
+        self.handle = h
+        self.max_level = ctx.lib.vo_pyr_max_level(h)
+        self._keep = None
+
+    def level_shape(self, level: int) -> Tuple[int, int]:
+        hh, ww, pp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        check(self.ctx.lib.vo_pyr_level_shape(self.handle, int(level), ctypes.byref(hh), ctypes.byref(ww),
+                                              ctypes.byref(pp)), "vo_pyr_level_shape")
+        return hh.value, ww.value
+
+    def build(self, imgs) -> "Pyramid":
+        """imgs: (H,W) or (B,H,W) uint8, numpy or torch-on-GPU (kept alive by this object)."""
+        if _is_torch(imgs):
+            import torch
+            assert imgs.dtype == torch.uint8 and imgs.is_cuda
+            t = imgs if imgs.dim() == 3 else imgs.unsqueeze(0)
+            if t.stride(2) != 1:
+                t = t.contiguous()
+            if tuple(t.shape) != (self.batch, self.height, self.width):
+                raise ValueError(f"Pyramid.build: expected {(self.batch, self.height, self.width)}, got {tuple(t.shape)}")
+            self._keep = t
+            check(self.ctx.lib.vo_pyr_build(self.ctx.handle, self.handle, _ptr(t), t.stride(1),
+                                            t.stride(0) if self.batch > 1 else t.stride(1) * self.height,
+                                            VO_MEM_DEVICE), "vo_pyr_build")
+        else:
+            a = np.ascontiguousarray(imgs, dtype=np.uint8)
+            if a.ndim == 2:
+                a = a[None]
+            if a.shape != (self.batch, self.height, self.width):
+                raise ValueError(f"Pyramid.build: expected {(self.batch, self.height, self.width)}, got {a.shape}")
+            check(self.ctx.lib.vo_pyr_build(self.ctx.handle, self.handle, _ptr(a), a.strides[1], a.strides[0],
+                                            VO_MEM_HOST), "vo_pyr_build")
+        return self
+
+    def download(self, image: int, level: int) -> np.ndarray:
+        h, w = self.level_shape(level)
+        out = np.empty((h, w), np.uint8)
+        check(self.ctx.lib.vo_pyr_download(self.ctx.handle, self.handle, int(image), int(level), _ptr(out)),
+              "vo_pyr_download")
+        return out
+
+    def close(self) -> None:
+        if self.handle:
+            self.ctx.lib.vo_pyr_destroy(self.handle)
+            self.handle = None
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def klt_track(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, max_iters: int = 10, eps: float = 0.001,
+              min_eig: float = 1e-2, init_pts=None, out=None):
+    """Batched pyramidal LK.  pts: (B,N,2) or (N,2) float32.
+
+    numpy in -> (next_pts, status, err) numpy, synchronous.
+    torch in -> torch outputs on the GPU, asynchronous; `out=(next_pts, status, err)` reuses buffers.
+    """
+    prm = KltParams(int(max_iters), float(eps), float(min_eig))
+    if _is_torch(pts):
+        import torch
+        p = pts.reshape(prev.batch, -1, 2)
+        assert p.dtype == torch.float32 and p.is_cuda and p.is_contiguous()
+        n = p.shape[1]
+        if out is None:
+            out = (torch.empty_like(p), torch.empty((prev.batch, n), dtype=torch.uint8, device=p.device),
+                   torch.empty((prev.batch, n), dtype=torch.float32, device=p.device))
+        o, s, e = out
+        check(ctx.lib.vo_klt_track(ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(init_pts), n,
+                                   ctypes.byref(prm), _ptr(o), _ptr(s), _ptr(e), VO_MEM_DEVICE), "vo_klt_track")
+        return o, s, e
+    p = np.ascontiguousarray(pts, dtype=np.float32).reshape(prev.batch, -1, 2)
+    n = p.shape[1]
+    ip = None if init_pts is None else np.ascontiguousarray(init_pts, dtype=np.float32).reshape(prev.batch, -1, 2)
+    o = np.zeros_like(p)
+    s = np.zeros((prev.batch, n), np.uint8)
+    e = np.zeros((prev.batch, n), np.float32)
+    check(ctx.lib.vo_klt_track(ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(ip), n, ctypes.byref(prm),
+                               _ptr(o), _ptr(s), _ptr(e), VO_MEM_HOST), "vo_klt_track")
+    return o, s, e
+
+
+def klt_track_fb(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, lam: float, max_iters: int = 10,
+                 eps: float = 0.001, min_eig: float = 1e-2):
+    """Forward-backward LK with the bidirectional test; returns (next_pts, mask)."""
+    prm = KltParams(int(max_iters), float(eps), float(min_eig))
+    if _is_torch(pts):
+        import torch
+        p = pts.reshape(prev.batch, -1, 2)
+        n = p.shape[1]
+        o = torch.empty_like(p)
+        m = torch.empty((prev.batch, n), dtype=torch.uint8, device=p.device)
+        check(ctx.lib.vo_klt_track_fb(ctx.handle, prev.handle, nxt.handle, _ptr(p), n, ctypes.byref(prm), float(lam),
+                                      _ptr(o), _ptr(m), VO_MEM_DEVICE), "vo_klt_track_fb")
+        return o, m
+    p = np.ascontiguousarray(pts, dtype=np.float32).reshape(prev.batch, -1, 2)
+    n = p.shape[1]
+    o = np.zeros_like(p)
+    m = np.zeros((prev.batch, n), np.uint8)
+    check(ctx.lib.vo_klt_track_fb(ctx.handle, prev.handle, nxt.handle, _ptr(p), n, ctypes.byref(prm), float(lam),
+                                  _ptr(o), _ptr(m), VO_MEM_HOST), "vo_klt_track_fb")
+    return o, m
