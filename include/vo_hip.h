@@ -94,6 +94,51 @@ int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
                     const float *prev_pts, int n, const vo_klt_params *params,
                     float lambda, float *next_pts, uint8_t *mask, int mem);
 
+/* ---- RANSAC hypothesis scoring --------------------------------------------
+ * vo_score_fundamental replaces the per-candidate error/inlier loop inside
+ * cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC, thr, conf, maxIters)
+ * (vo_pipeline/bootstrap.py:246-252): err = (float)max(d1^2/|l1|^2, d2^2/|l2|^2)
+ * in float64, inlier iff err <= (float)(thr*thr).
+ * m1, m2: (n,2) float32; F: (H,9) float64 row-major; counts: (H) int32;
+ * masks: (H,n) uint8 or NULL.
+ */
+int vo_score_fundamental(vo_ctx *ctx, const float *m1, const float *m2, int n, const double *F, int H,
+                         double thr, int32_t *counts, uint8_t *masks, int mem);
+/* vo_score_pnp replaces the per-candidate reprojection/inlier loop inside
+ * cv.solvePnPRansac(pointcloud, img_key_points, K, None, flags=P3P, ...)
+ * (vo_pipeline/poseEstimation.py:61-69): projection in float64 without
+ * distortion, err = (float)|x - proj|^2, inlier iff err <= (float)(thr*thr).
+ * X: (n,3) float32; x: (n,2) float32; K: (3,3) float64 row-major, ALWAYS a host
+ * pointer (passed to the kernel by value);
+ * Rt: (H,12) float64 row-major [R|t] world->camera.
+ */
+int vo_score_pnp(vo_ctx *ctx, const float *X, const float *x, int n, const double *K, const double *Rt, int H,
+                 double thr, int32_t *counts, uint8_t *masks, int mem);
+
+/* ---- bundle-adjustment residual and normal equations ------------------------
+ * vo_ba_residual replaces BundleAdjustment._fun (with _reproject/_rotate),
+ * vo_pipeline/bundleAdjustment.py:14-45: params = [F x (rvec, t) | P x (X,Y,Z)]
+ * float64, camera_indices / point_indices (O) int64, observations (O,2) float64,
+ * K (3,3) float64 row-major (ALWAYS a host pointer).  r: (2O) interleaved
+ * residuals; *cost = 0.5 * sum r^2 (the quantity scipy's TRF minimises for the
+ * call at bundleAdjustment.py:96-97).  cost lives in the same memory space as r.
+ * An observation whose indices are out of range yields NaN (VO_MEM_DEVICE) or
+ * VO_EINVAL (VO_MEM_HOST); it never touches memory out of bounds.
+ */
+int vo_ba_residual(vo_ctx *ctx, const double *params, int F, int P, const int64_t *camera_indices,
+                   const int64_t *point_indices, const double *obs, int O, const double *K,
+                   double *r, double *cost, int mem);
+/* vo_ba_normal_eq additionally builds the normal equations from analytic
+ * Jacobian blocks (the reference lets scipy difference _fun through the sparsity
+ * of bundleAdjustment.py:47-67 instead): Hcc (F,6,6), Hpp (P,3,3), Hcp (O,6,3)
+ * per observation, g (6F+3P) = J^T r.  Observations i < obs_start contribute no
+ * Jacobian rows: obs_start = number of observations of the first int(F/4)+1
+ * cameras, exactly the rows bundleAdjustment.py:54-65 leaves empty.
+ */
+int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, const int64_t *camera_indices,
+                    const int64_t *point_indices, const double *obs, int O, const double *K, int obs_start,
+                    double *r, double *cost, double *Hcc, double *Hpp, double *Hcp, double *g, int mem);
+
 #ifdef __cplusplus
 }
 #endif

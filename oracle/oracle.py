@@ -30,6 +30,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _declare(_lib)
+        _declare_more(_lib)
     return _lib
 
 
@@ -54,6 +55,21 @@ def _declare(L):
     L.vo_or_klt.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int,
                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_float,
                             _f32p, _u8p, _f32p]
+
+
+def _declare_more(L):
+    L.vo_or_score_fundamental.restype = None
+    L.vo_or_score_fundamental.argtypes = [_f32p, _f32p, ctypes.c_int, _f64p, ctypes.c_int, ctypes.c_double, _i32p, _u8p]
+    L.vo_or_score_pnp.restype = None
+    L.vo_or_score_pnp.argtypes = [_f32p, _f32p, ctypes.c_int, _f64p, _f64p, ctypes.c_int, ctypes.c_double, _i32p, _u8p]
+    L.vo_or_ba_residual.restype = ctypes.c_double
+    L.vo_or_ba_residual.argtypes = [_f64p, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _f64p, ctypes.c_int, _f64p, _f64p]
+    L.vo_or_ba_jacobian.restype = None
+    L.vo_or_ba_jacobian.argtypes = [_f64p, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _f64p, ctypes.c_int, _f64p,
+                                    ctypes.c_int, _f64p, _f64p]
+    L.vo_or_ba_normal_eq.restype = ctypes.c_double
+    L.vo_or_ba_normal_eq.argtypes = [_f64p, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _f64p, ctypes.c_int, _f64p,
+                                     ctypes.c_int, _f64p, _f64p, _f64p, _f64p, _f64p]
 
 
 def _p(a, t):
@@ -109,3 +125,70 @@ def klt(img0, img1, pts, win=21, max_level=8, max_iters=10, eps=0.001, min_eig=1
     lib().vo_or_klt(_p(img0, _u8p), _p(img1, _u8p), w, h, w, _p(pts, _f32p), ip, n, int(win), int(max_level),
                     int(max_iters), float(eps), float(min_eig), _p(out, _f32p), _p(st, _u8p), _p(err, _f32p))
     return out, st, err
+
+
+def score_fundamental(m1, m2, F, thr, want_masks=True):
+    """-> (counts (H,) i32, masks (H,n) u8 or None)."""
+    m1 = np.ascontiguousarray(m1, np.float32).reshape(-1, 2)
+    m2 = np.ascontiguousarray(m2, np.float32).reshape(-1, 2)
+    F = np.ascontiguousarray(F, np.float64).reshape(-1, 9)
+    n, H = m1.shape[0], F.shape[0]
+    counts = np.zeros(H, np.int32)
+    masks = np.zeros((H, n), np.uint8) if want_masks else None
+    lib().vo_or_score_fundamental(_p(m1, _f32p), _p(m2, _f32p), n, _p(F, _f64p), H, float(thr), _p(counts, _i32p),
+                                  _p(masks, _u8p) if want_masks else None)
+    return counts, masks
+
+
+def score_pnp(X, x, K, Rt, thr, want_masks=True):
+    X = np.ascontiguousarray(X, np.float32).reshape(-1, 3)
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+    Rt = np.ascontiguousarray(Rt, np.float64).reshape(-1, 12)
+    n, H = X.shape[0], Rt.shape[0]
+    counts = np.zeros(H, np.int32)
+    masks = np.zeros((H, n), np.uint8) if want_masks else None
+    lib().vo_or_score_pnp(_p(X, _f32p), _p(x, _f32p), n, _p(K, _f64p), _p(Rt, _f64p), H, float(thr),
+                          _p(counts, _i32p), _p(masks, _u8p) if want_masks else None)
+    return counts, masks
+
+
+def _ba_args(params, F, P, ci, pi, obs, K):
+    params = np.ascontiguousarray(params, np.float64)
+    ci = np.ascontiguousarray(ci, np.int64); pi = np.ascontiguousarray(pi, np.int64)
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+    assert params.size == 6 * F + 3 * P and ci.size == pi.size == obs.shape[0]
+    return params, ci, pi, obs, K
+
+
+def ba_residual(params, F, P, ci, pi, obs, K):
+    """-> (r (2O,), cost)."""
+    params, ci, pi, obs, K = _ba_args(params, F, P, ci, pi, obs, K)
+    O = ci.size
+    r = np.zeros(2 * O)
+    cost = lib().vo_or_ba_residual(_p(params, _f64p), F, P, _p(ci, _i64p), _p(pi, _i64p), _p(obs, _f64p), O,
+                                   _p(K, _f64p), _p(r, _f64p))
+    return r, cost
+
+
+def ba_jacobian(params, F, P, ci, pi, obs, K, obs_start=0):
+    """-> (Jc (O,2,6), Jp (O,2,3))."""
+    params, ci, pi, obs, K = _ba_args(params, F, P, ci, pi, obs, K)
+    O = ci.size
+    Jc = np.zeros((O, 2, 6)); Jp = np.zeros((O, 2, 3))
+    lib().vo_or_ba_jacobian(_p(params, _f64p), F, P, _p(ci, _i64p), _p(pi, _i64p), _p(obs, _f64p), O, _p(K, _f64p),
+                            int(obs_start), _p(Jc, _f64p), _p(Jp, _f64p))
+    return Jc, Jp
+
+
+def ba_normal_eq(params, F, P, ci, pi, obs, K, obs_start=0):
+    """-> dict(r, cost, Hcc (F,6,6), Hpp (P,3,3), Hcp (O,6,3), g (6F+3P,))."""
+    params, ci, pi, obs, K = _ba_args(params, F, P, ci, pi, obs, K)
+    O = ci.size
+    r = np.zeros(2 * O); Hcc = np.zeros((F, 6, 6)); Hpp = np.zeros((P, 3, 3)); Hcp = np.zeros((O, 6, 3))
+    g = np.zeros(6 * F + 3 * P)
+    cost = lib().vo_or_ba_normal_eq(_p(params, _f64p), F, P, _p(ci, _i64p), _p(pi, _i64p), _p(obs, _f64p), O,
+                                    _p(K, _f64p), int(obs_start), _p(r, _f64p), _p(Hcc, _f64p), _p(Hpp, _f64p),
+                                    _p(Hcp, _f64p), _p(g, _f64p))
+    return dict(r=r, cost=cost, Hcc=Hcc, Hpp=Hpp, Hcp=Hcp, g=g)

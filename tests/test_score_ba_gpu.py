@@ -1,0 +1,144 @@
+"""GPU parity through the C-ABI: hypothesis scoring must be bit-exact against the
+CPU oracle (counts and masks); BA residual/cost/normal equations within 1e-6
+relative on cost (in practice ~1e-13: float64, atomics reorder sums)."""
+import os
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COST_RTOL = 1e-6
+
+
+@pytest.mark.parametrize("n,H,thr", [(3000, 2048, 0.1), (500, 33, 0.5), (1, 1, 0.1), (1025, 5, 0.1), (64, 300, 2.0)])
+def test_score_fundamental_bit_exact(oracle, ctx, n, H, thr):
+    from visual_odometry_amd import hip
+    sc = synth.two_view_scene(n=n, seed=7)
+    Fh = synth.fundamental_hypotheses(sc, H, seed=7)
+    rc, rm = oracle.score_fundamental(sc["m1"], sc["m2"], Fh, thr)
+    gc, gm = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh, thr)
+    np.testing.assert_array_equal(gc, rc)
+    np.testing.assert_array_equal(gm, rm)
+    gc2, gm2 = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh, thr, want_masks=False)
+    assert gm2 is None
+    np.testing.assert_array_equal(gc2, rc)
+
+
+@pytest.mark.parametrize("n,H,thr", [(3000, 2048, 1.0), (400, 17, 1.0), (2049, 3, 0.5)])
+def test_score_pnp_bit_exact(oracle, ctx, n, H, thr):
+    from visual_odometry_amd import hip
+    sc = synth.two_view_scene(n=n, seed=9)
+    Rt = synth.pose_hypotheses(sc, H, seed=9)
+    rc, rm = oracle.score_pnp(sc["X"], sc["m2"], sc["K"], Rt, thr)
+    gc, gm = hip.score_pnp(ctx, sc["X"], sc["m2"], sc["K"], Rt, thr)
+    np.testing.assert_array_equal(gc, rc)
+    np.testing.assert_array_equal(gm, rm)
+    assert rc[0] > 0.4 * n
+
+
+def test_score_degenerate_models(oracle, ctx):
+    """Zero / NaN models and points behind the camera follow the same comparison rules."""
+    from visual_odometry_amd import hip
+    sc = synth.two_view_scene(n=200, seed=1)
+    Fh = np.stack([np.zeros((3, 3)), np.full((3, 3), np.nan), sc["F"], np.eye(3)])
+    rc, rm = oracle.score_fundamental(sc["m1"], sc["m2"], Fh, 0.1)
+    gc, gm = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh, 0.1)
+    np.testing.assert_array_equal(gc, rc); np.testing.assert_array_equal(gm, rm)
+    Rt = np.stack([np.zeros((3, 4)), np.hstack([np.eye(3), [[0], [0], [-100.0]]]), np.hstack([sc["R"], sc["t"][:, None]])])
+    rc, rm = oracle.score_pnp(sc["X"], sc["m2"], sc["K"], Rt, 1.0)
+    gc, gm = hip.score_pnp(ctx, sc["X"], sc["m2"], sc["K"], Rt, 1.0)
+    np.testing.assert_array_equal(gc, rc); np.testing.assert_array_equal(gm, rm)
+
+
+def test_score_device_buffers_and_empty(oracle, ctx):
+    import torch
+    from visual_odometry_amd import hip
+    sc = synth.two_view_scene(n=777, seed=2)
+    Fh = synth.fundamental_hypotheses(sc, 40, seed=2)
+    rc, rm = oracle.score_fundamental(sc["m1"], sc["m2"], Fh, 0.1)
+    gc, gm = hip.score_fundamental(ctx, torch.from_numpy(sc["m1"]).cuda(), torch.from_numpy(sc["m2"]).cuda(),
+                                   torch.from_numpy(Fh).cuda(), 0.1)
+    ctx.sync()
+    np.testing.assert_array_equal(gc.cpu().numpy(), rc); np.testing.assert_array_equal(gm.cpu().numpy(), rm)
+    c, m = hip.score_fundamental(ctx, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), Fh, 0.1)
+    assert (c == 0).all() and m.shape == (40, 0)
+    c, m = hip.score_fundamental(ctx, sc["m1"], sc["m2"], np.zeros((0, 3, 3)), 0.1)
+    assert c.shape == (0,)
+    with pytest.raises(ValueError):
+        hip.score_fundamental(ctx, sc["m1"], sc["m2"][:10], Fh, 0.1)
+
+
+@pytest.mark.parametrize("name", ["ba_small", "ba_mid", "ba_frozen8"])
+def test_ba_matches_golden_and_oracle(oracle, ctx, name):
+    from visual_odometry_amd import hip
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    F, P, ci, pi = int(d["F"]), int(d["P"]), d["ci"], d["pi"]
+    r, cost = hip.ba_residual(ctx, d["x"], F, P, ci, pi, d["obs"], d["K"])
+    np.testing.assert_allclose(r, d["r"], rtol=0, atol=1e-8)                # reference _fun output
+    assert abs(cost - float(d["cost"])) <= COST_RTOL * float(d["cost"])
+    start = int(np.count_nonzero(ci < int(d["n_fixed"])))
+    ne = hip.ba_normal_eq(ctx, d["x"], F, P, ci, pi, d["obs"], d["K"], start)
+    ref = oracle.ba_normal_eq(d["x"], F, P, ci, pi, d["obs"], d["K"], start)
+    assert abs(ne["cost"] - ref["cost"]) <= 1e-12 * ref["cost"]
+    np.testing.assert_allclose(ne["r"], ref["r"], rtol=0, atol=1e-9)
+    for k in ("Hcc", "Hpp", "Hcp", "g"):
+        scale = np.abs(ref[k]).max()
+        assert np.abs(ne[k] - ref[k]).max() <= 1e-10 * scale, k
+    assert (ne["Hcp"][:start] == 0).all()
+
+
+def test_ba_config4_shape(oracle, ctx):
+    """10 keyframes x 5000 landmarks, all visible (50 000 observations), 3 frozen cameras."""
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=10, P=5000, seed=0)
+    F, P = pb["F"], pb["P"]
+    start = int(np.count_nonzero(pb["ci"] < int(F / 4) + 1))
+    assert pb["ci"].size == 50000 and start == 15000
+    ne = hip.ba_normal_eq(ctx, pb["x"], F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], start)
+    ref = oracle.ba_normal_eq(pb["x"], F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], start)
+    assert abs(ne["cost"] - ref["cost"]) <= 1e-12 * ref["cost"]
+    for k in ("Hcc", "Hpp", "Hcp", "g", "r"):
+        scale = np.abs(ref[k]).max()
+        assert np.abs(ne[k] - ref[k]).max() <= 1e-10 * scale, k
+    assert (ne["Hcc"][:3] == 0).all() and np.abs(ne["Hcc"][3:]).min(axis=(1, 2)).max() >= 0
+    # unsorted observation order (camera blocks fall back to per-lane atomics) gives the same sums
+    perm = np.random.default_rng(0).permutation(50000)
+    ne2 = hip.ba_normal_eq(ctx, pb["x"], F, P, pb["ci"][perm], pb["pi"][perm], pb["obs"][perm], pb["K"], 0)
+    ref2 = oracle.ba_normal_eq(pb["x"], F, P, pb["ci"][perm], pb["pi"][perm], pb["obs"][perm], pb["K"], 0)
+    for k in ("Hcc", "Hpp", "g"):
+        assert np.abs(ne2[k] - ref2[k]).max() <= 1e-10 * np.abs(ref2[k]).max(), k
+
+
+def test_ba_device_and_edge_cases(oracle, ctx):
+    import torch
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=4, P=100, visibility=0.6, seed=3)
+    F, P = pb["F"], pb["P"]
+    ref = oracle.ba_normal_eq(pb["x"], F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], 0)
+    tx = torch.from_numpy(pb["x"]).cuda(); tci = torch.from_numpy(pb["ci"]).cuda(); tpi = torch.from_numpy(pb["pi"]).cuda()
+    tobs = torch.from_numpy(pb["obs"].astype(np.float64)).cuda()
+    ne = hip.ba_normal_eq(ctx, tx, F, P, tci, tpi, tobs, pb["K"], 0)
+    ctx.sync()
+    assert abs(float(ne["cost"].item()) - ref["cost"]) <= 1e-12 * ref["cost"]
+    np.testing.assert_allclose(ne["g"].cpu().numpy(), ref["g"], rtol=1e-9, atol=1e-6)
+    # zero rotation vector: the theta == 0 branch
+    x0 = pb["x"].copy(); x0[0:3] = 0
+    r, cost = hip.ba_residual(ctx, x0, F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"])
+    rr, rcost = oracle.ba_residual(x0, F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"])
+    np.testing.assert_allclose(r, rr, atol=1e-9); assert np.isfinite(r).all()
+    ne0 = hip.ba_normal_eq(ctx, x0, F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], 0)
+    ref0 = oracle.ba_normal_eq(x0, F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], 0)
+    assert np.abs(ne0["Hcc"] - ref0["Hcc"]).max() <= 1e-10 * np.abs(ref0["Hcc"]).max()
+    # empty observation set, bad indices
+    r, cost = hip.ba_residual(ctx, pb["x"], F, P, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 2)), pb["K"])
+    assert r.size == 0 and cost == 0
+    bad = pb["ci"].copy(); bad[5] = F
+    with pytest.raises(ValueError):
+        hip.ba_residual(ctx, pb["x"], F, P, bad, pb["pi"], pb["obs"], pb["K"])
+    tb = torch.from_numpy(bad).cuda()
+    r, _ = hip.ba_residual(ctx, tx, F, P, tb, tpi, tobs, pb["K"])
+    ctx.sync()
+    assert torch.isnan(r[10]).item() and torch.isfinite(r[12]).item()

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own numpy/scipy functions.
+
+Runs only in the build container (needs /root/reference).  The reference modules
+`import cv2` at the top although the functions exercised here never call it; cv2
+is not installed, so an EMPTY module object named cv2 is registered first -- it
+provides no functionality.  Only inputs and outputs are stored (fixtures are
+data); no reference source is copied.
+
+Functions exercised (reference file:line):
+  BundleAdjustment._rotate / _reproject / _fun      vo_pipeline/bundleAdjustment.py:14-45
+  BundleAdjustment._bundle_adjustment_sparsity      vo_pipeline/bundleAdjustment.py:47-67
+  scipy 2-point FD Jacobian through that sparsity   (what least_squares does at :96-97)
+  BootstrapInitializer._linear_triangulation        vo_pipeline/bootstrap.py:141-156
+  BootstrapInitializer._transform_matrix            vo_pipeline/bootstrap.py:76-138
+  ContinuousVO._baseline_uncertainty                vo_pipeline/continuousVO.py:249-271
+  utils.matrix.hom_inv / skew                       utils/matrix.py:4-40
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def rodrigues(rv):
+    th = np.linalg.norm(rv)
+    if th == 0:
+        return np.eye(3)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+
+def ba_problem(F, P, vis, seed, K):
+    """Seeded scene: points in front of cameras moving along z; observations with 0.5 px noise."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-20, -3, 6], [20, 3, 60], (P, 3))
+    cams = np.zeros((F, 6))
+    cams[:, :3] = rng.normal(0, 0.01, (F, 3))
+    cams[:, 5] = -0.8 * np.arange(F)
+    cams[:, 3:5] = rng.normal(0, 0.05, (F, 2))
+    ci, pi, obs = [], [], []
+    for f in range(F):
+        R = rodrigues(cams[f, :3])
+        for p in range(P):
+            if rng.uniform() > vis:
+                continue
+            Xc = R @ pts[p] + cams[f, 3:]
+            uv = (K @ Xc)[:2] / Xc[2]
+            ci.append(f); pi.append(p); obs.append(uv + rng.normal(0, 0.5, 2))
+    ci = np.asarray(ci, np.int64); pi = np.asarray(pi, np.int64)
+    obs = np.asarray(obs, np.float32)
+    # perturbed parameter vector (what the optimiser would be evaluated at)
+    x = np.hstack([(cams + rng.normal(0, 1e-3, cams.shape)).ravel(), (pts + rng.normal(0, 0.05, pts.shape)).ravel()])
+    return x, ci, pi, obs
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, REF)
+    sys.modules["cv2"] = types.ModuleType("cv2")   # empty: nothing below calls into it
+    from vo_pipeline.bundleAdjustment import BundleAdjustment
+    from vo_pipeline.bootstrap import BootstrapInitializer
+    from vo_pipeline.continuousVO import ContinuousVO
+    from utils.matrix import hom_inv, skew
+    from scipy.optimize._numdiff import approx_derivative, group_columns
+
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], dtype=np.float32)
+    ba = BundleAdjustment(K)
+
+    # ---- BA residual / sparsity / FD Jacobian --------------------------------
+    for name, (F, P, vis, seed) in {"ba_small": (3, 20, 1.0, 0), "ba_mid": (6, 150, 0.7, 1),
+                                    "ba_frozen8": (8, 60, 0.8, 2)}.items():
+        x, ci, pi, obs = ba_problem(F, P, vis, seed, K.astype(np.float64))
+        r = ba._fun(x, F, P, ci, pi, obs)
+        A = ba._bundle_adjustment_sparsity(F, P, ci, pi)
+        groups = group_columns(A)
+        J = approx_derivative(ba._fun, x, method="2-point", sparsity=(A, groups), args=(F, P, ci, pi, obs)).tocsr()
+        Acsr = A.tocsr()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), F=F, P=P, K=K, x=x, ci=ci, pi=pi, obs=obs, r=r,
+                            cost=0.5 * float(r @ r), A_indices=Acsr.indices, A_indptr=Acsr.indptr,
+                            J_data=J.data, J_indices=J.indices, J_indptr=J.indptr,
+                            n_fixed=int(F / 4) + 1)
+        print(name, "O =", ci.size, "cost =", 0.5 * float(r @ r), "nnz(A) =", Acsr.nnz)
+
+    # ---- _rotate edge cases (theta == 0 -> points unchanged) ------------------
+    rng = np.random.default_rng(3)
+    rv = rng.normal(0, 1, (12, 3)); rv[0] = 0; rv[1] = [1e-12, 0, 0]; rv[2] = [0, np.pi, 0]; rv[3] = [1e-7, -1e-7, 2e-7]
+    X = rng.normal(0, 10, (12, 3))
+    np.savez_compressed(os.path.join(OUT, "rotate.npz"), rv=rv, X=X, out=ba._rotate(X, rv))
+
+    # ---- two-view geometry ----------------------------------------------------
+    rng = np.random.default_rng(4)
+    Kd = K.astype(np.float64)
+    n = 40
+    Pw = rng.uniform([-8, -3, 8], [8, 3, 40], (n, 3))
+    R = rodrigues(np.array([0.01, -0.03, 0.005])); t = np.array([0.9, 0.05, 0.2]); t /= np.linalg.norm(t)
+    M1 = (K @ np.eye(3, 4, dtype=np.float32))
+    M2 = (Kd @ np.hstack([R, t[:, None]]))
+    p1 = (Kd @ Pw.T).T; p1 /= p1[:, 2:]
+    p2 = (Kd @ (R @ Pw.T + t[:, None])).T; p2 /= p2[:, 2:]
+    p1 = p1.astype(np.float32); p2 = p2.astype(np.float32)
+    tri = BootstrapInitializer._linear_triangulation(p1, p2, M1, M2)
+    tx = skew(t.astype(np.float32)).astype(np.float64)
+    E = tx @ R
+    Fm = np.linalg.inv(Kd).T @ E @ np.linalg.inv(Kd)
+    boot = object.__new__(BootstrapInitializer)
+    boot.K = K; boot.max_point_dist = 50
+    T, cloud, mask = boot._transform_matrix(Fm, p1, p2)
+    np.savez_compressed(os.path.join(OUT, "two_view.npz"), K=K, p1=p1, p2=p2, M1=M1, M2=M2, tri=tri, F=Fm, T=T,
+                        cloud=cloud, mask=mask, R_true=R, t_true=t, max_point_dist=50)
+    print("two_view: tri err", np.abs(tri[:, :3] - Pw).max(), "mask", mask.sum())
+
+    # ---- baseline uncertainty / hom_inv --------------------------------------
+    vo = object.__new__(ContinuousVO)
+    T0 = np.eye(4); T0[:3, :3] = rodrigues(np.array([0.02, 0.01, -0.03])); T0[:3, 3] = [0.1, -0.2, 0.3]
+    T1 = np.eye(4); T1[:3, :3] = rodrigues(np.array([0.03, -0.02, 0.01])); T1[:3, 3] = [0.5, -0.1, -1.2]
+    lm = rng.uniform([-10, -3, -5], [10, 3, 40], (30, 3)).astype(np.float32)
+    bu = vo._baseline_uncertainty(T0, T1, lm)
+    bu_none = vo._baseline_uncertainty(T0, T1, lm * np.array([1, 1, -1], np.float32) - np.array([0, 0, 100], np.float32))
+    np.savez_compressed(os.path.join(OUT, "baseline.npz"), T0=T0, T1=T1, landmarks=lm, uncertainty=bu,
+                        uncertainty_none=bu_none, T0_inv=hom_inv(T0), skew_v=np.array([1.0, 2.0, 3.0]),
+                        skew_m=skew(np.array([1.0, 2.0, 3.0])))
+    print("baseline", bu, bu_none)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,12 +41,12 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
 extern "C" int vo_ctx_destroy(vo_ctx *ctx)
 {
     if (!ctx) return VO_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->stage)
-        if (b.ptr) hipFree(b.ptr);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
     return VO_OK;
 }

@@ -1,0 +1,134 @@
+// Batched RANSAC hypothesis scoring: every (hypothesis, correspondence) pair is
+// independent.  One wavefront scores one hypothesis against a chunk of points:
+// the model sits in scalar registers, lanes stride over the points with
+// coalesced loads, inliers are counted with a 64-bit ballot + popcount and one
+// integer atomic per wave (integer sums are order-independent, so counts and
+// masks are bit-reproducible).  float64 arithmetic in source order with
+// contraction off, as the CPU routines this replaces.
+//
+// Replaces the per-candidate scoring loops inside
+//   cv2.findFundamentalMat(..., FM_RANSAC, ...)  vo_pipeline/bootstrap.py:246-252
+//   cv.solvePnPRansac(..., flags=P3P, ...)       vo_pipeline/poseEstimation.py:61-69
+#include "vo_internal.h"
+
+#define SC_WAVES 4
+#define SC_CHUNK 1024  // points per wave
+
+__device__ __forceinline__ double std_max(double x, double y) { return (x < y) ? y : x; }
+
+template <bool PNP>
+__global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__restrict__ pa, const float *__restrict__ pb,
+                                                              int n, const double *__restrict__ models, int H,
+                                                              double fx, double fy, double cx, double cy, float t,
+                                                              int *__restrict__ counts, uint8_t *__restrict__ masks)
+{
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * SC_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (h >= H) return;
+    constexpr int MS = PNP ? 12 : 9;
+    double m[MS];
+#pragma unroll
+    for (int k = 0; k < MS; ++k) m[k] = models[(int64_t)h * MS + k];
+    const int i0 = blockIdx.y * SC_CHUNK;
+    const int i1 = min(n, i0 + SC_CHUNK);
+    int good = 0;
+    for (int i = i0 + lane; i < i1; i += 64) {
+        bool in;
+        if (PNP) {
+            double Xw = pa[3 * i], Yw = pa[3 * i + 1], Zw = pa[3 * i + 2];
+            double xc = m[0] * Xw + m[1] * Yw + m[2] * Zw + m[3];
+            double yc = m[4] * Xw + m[5] * Yw + m[6] * Zw + m[7];
+            double zc = m[8] * Xw + m[9] * Yw + m[10] * Zw + m[11];
+            zc = zc ? 1. / zc : 1;
+            xc *= zc;
+            yc *= zc;
+            float u = (float)(xc * fx + cx), v = (float)(yc * fy + cy);
+            float du = pb[2 * i] - u, dv = pb[2 * i + 1] - v;
+            float err = du * du + dv * dv;
+            in = err <= t;
+        } else {
+            double x1 = pa[2 * i], y1 = pa[2 * i + 1], x2 = pb[2 * i], y2 = pb[2 * i + 1];
+            double a, b, c, d1, d2, s1, s2;
+            a = m[0] * x1 + m[1] * y1 + m[2];
+            b = m[3] * x1 + m[4] * y1 + m[5];
+            c = m[6] * x1 + m[7] * y1 + m[8];
+            s2 = 1. / (a * a + b * b);
+            d2 = x2 * a + y2 * b + c;
+            a = m[0] * x2 + m[3] * y2 + m[6];
+            b = m[1] * x2 + m[4] * y2 + m[7];
+            c = m[2] * x2 + m[5] * y2 + m[8];
+            s1 = 1. / (a * a + b * b);
+            d1 = x1 * a + y1 * b + c;
+            float err = (float)std_max(d1 * d1 * s1, d2 * d2 * s2);
+            in = err <= t;
+        }
+        good += __popcll(__ballot(in));
+        if (masks) masks[(int64_t)h * n + i] = in ? 1 : 0;
+    }
+    if (lane == 0) {
+        if (gridDim.y == 1) counts[h] = good;
+        else atomicAdd(&counts[h], good);
+    }
+}
+
+template <bool PNP>
+static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, const double *models, int H,
+                        const double *K, double thr, int *counts, uint8_t *masks, int mem, const char *who)
+{
+    VO_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
+    VO_REQUIRE(n >= 0 && H >= 0, "%s: n=%d H=%d", who, n, H);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "%s: bad mem flag %d", who, mem);
+    if (H == 0) return VO_OK;
+    VO_REQUIRE(models && counts, "%s: NULL model/count buffer", who);
+    VO_REQUIRE(n == 0 || (pa && pb), "%s: NULL point buffer", who);
+    VO_REQUIRE(!PNP || K, "%s: K is NULL", who);
+    VO_REQUIRE((int64_t)H * (int64_t)(n > 0 ? n : 1) < (1ll << 40), "%s: problem too large", who);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const float t = (float)(thr * thr);
+    constexpr int MS = PNP ? 12 : 9, PA = PNP ? 3 : 2;
+    const float *d_pa = pa, *d_pb = pb;
+    const double *d_m = models;
+    int *d_c = counts;
+    uint8_t *d_k = masks;
+    double Kh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rc;
+    if (mem == VO_MEM_HOST) {
+        void *p;
+        if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * PA * 4, &p))) return rc; d_pa = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 2 * 4, &p))) return rc; d_pb = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 2, (size_t)H * MS * 8, &p))) return rc; d_m = (const double *)p;
+        if ((rc = vo_stage_reserve(ctx, 3, (size_t)H * 4, &p))) return rc; d_c = (int *)p;
+        if (masks) { if ((rc = vo_stage_reserve(ctx, 4, (size_t)H * n, &p))) return rc; d_k = (uint8_t *)p; }
+        if (n) {
+            VO_HIP_CHECK(hipMemcpyAsync((void *)d_pa, pa, (size_t)n * PA * 4, hipMemcpyHostToDevice, ctx->stream));
+            VO_HIP_CHECK(hipMemcpyAsync((void *)d_pb, pb, (size_t)n * 2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        VO_HIP_CHECK(hipMemcpyAsync((void *)d_m, models, (size_t)H * MS * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (PNP) memcpy(Kh, K, sizeof(Kh));  // K is always a host pointer: it travels as kernel arguments
+    const int chunks = n > 0 ? (n + SC_CHUNK - 1) / SC_CHUNK : 1;
+    VO_REQUIRE(chunks <= 65535, "%s: n=%d exceeds %d points", who, n, 65535 * SC_CHUNK);
+    if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(d_c, 0, (size_t)H * 4, ctx->stream));
+    dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
+    hipLaunchKernelGGL(score_kernel<PNP>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, d_pa, d_pb, n, d_m, H, Kh[0], Kh[4],
+                       Kh[2], Kh[5], t, d_c, d_k);
+    VO_HIP_CHECK(hipGetLastError());
+    if (mem == VO_MEM_HOST) {
+        VO_HIP_CHECK(hipMemcpyAsync(counts, d_c, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (masks && n) VO_HIP_CHECK(hipMemcpyAsync(masks, d_k, (size_t)H * n, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_score_fundamental(vo_ctx *ctx, const float *m1, const float *m2, int n, const double *F, int H,
+                                    double thr, int32_t *counts, uint8_t *masks, int mem)
+{
+    return score_common<false>(ctx, m1, m2, n, F, H, nullptr, thr, counts, masks, mem, "vo_score_fundamental");
+}
+
+extern "C" int vo_score_pnp(vo_ctx *ctx, const float *X, const float *x, int n, const double *K, const double *Rt,
+                            int H, double thr, int32_t *counts, uint8_t *masks, int mem)
+{
+    return score_common<true>(ctx, X, x, n, Rt, H, K, thr, counts, masks, mem, "vo_score_pnp");
+}

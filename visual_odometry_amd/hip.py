@@ -187,3 +187,103 @@ def klt_track_fb(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, lam: float, max
     check(ctx.lib.vo_klt_track_fb(ctx.handle, prev.handle, nxt.handle, _ptr(p), n, ctypes.byref(prm), float(lam),
                                   _ptr(o), _ptr(m), VO_MEM_HOST), "vo_klt_track_fb")
     return o, m
+
+
+def _k_host(K) -> np.ndarray:
+    if _is_torch(K):
+        K = K.detach().cpu().numpy()
+    return np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+
+
+def _score(ctx, fn, pa, pb, models, thr, want_masks, K=None, pa_cols=2, ms=9):
+    if _is_torch(pa):
+        import torch
+        pa = pa.reshape(-1, pa_cols); pb = pb.reshape(-1, 2); models = models.reshape(-1, ms)
+        assert pa.dtype == torch.float32 and pb.dtype == torch.float32 and models.dtype == torch.float64
+        assert pa.is_contiguous() and pb.is_contiguous() and models.is_contiguous()
+        n, H = pa.shape[0], models.shape[0]
+        counts = torch.empty(H, dtype=torch.int32, device=pa.device)
+        masks = torch.empty((H, n), dtype=torch.uint8, device=pa.device) if want_masks else None
+        mem = VO_MEM_DEVICE
+    else:
+        pa = np.ascontiguousarray(pa, np.float32).reshape(-1, pa_cols)
+        pb = np.ascontiguousarray(pb, np.float32).reshape(-1, 2)
+        models = np.ascontiguousarray(models, np.float64).reshape(-1, ms)
+        n, H = pa.shape[0], models.shape[0]
+        counts = np.zeros(H, np.int32)
+        masks = np.zeros((H, n), np.uint8) if want_masks else None
+        mem = VO_MEM_HOST
+    if pb.shape[0] != n:
+        raise ValueError(f"{fn}: {n} vs {pb.shape[0]} correspondences")
+    f = getattr(ctx.lib, fn)
+    if K is None:
+        rc = f(ctx.handle, _ptr(pa), _ptr(pb), n, _ptr(models), H, float(thr), _ptr(counts), _ptr(masks), mem)
+    else:
+        Kh = _k_host(K)
+        rc = f(ctx.handle, _ptr(pa), _ptr(pb), n, Kh.ctypes.data_as(_lib.c_f64p), _ptr(models), H, float(thr),
+               _ptr(counts), _ptr(masks), mem)
+    check(rc, fn)
+    return counts, masks
+
+
+def score_fundamental(ctx: Context, m1, m2, F, thr: float, want_masks: bool = True):
+    """Inlier counts (H,) int32 and masks (H,n) uint8 of H fundamental-matrix candidates F (H,3,3) f64."""
+    return _score(ctx, "vo_score_fundamental", m1, m2, F, thr, want_masks)
+
+
+def score_pnp(ctx: Context, X, x, K, Rt, thr: float, want_masks: bool = True):
+    """Inlier counts and masks of H pose candidates Rt (H,3,4) f64 for 3-D points X (n,3) and pixels x (n,2)."""
+    return _score(ctx, "vo_score_pnp", X, x, Rt, thr, want_masks, K=K, pa_cols=3, ms=12)
+
+
+def _ba_prepare(params, F, P, ci, pi, obs):
+    if _is_torch(params):
+        import torch
+        assert params.dtype == torch.float64 and obs.dtype == torch.float64
+        assert ci.dtype == torch.int64 and pi.dtype == torch.int64
+        obs = obs.reshape(-1, 2)
+        for t in (params, ci, pi, obs):
+            assert t.is_cuda and t.is_contiguous()
+        return params, ci, pi, obs, VO_MEM_DEVICE
+    params = np.ascontiguousarray(params, np.float64).ravel()
+    ci = np.ascontiguousarray(ci, np.int64).ravel()
+    pi = np.ascontiguousarray(pi, np.int64).ravel()
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+    return params, ci, pi, obs, VO_MEM_HOST
+
+
+def ba_residual(ctx: Context, params, F: int, P: int, ci, pi, obs, K):
+    """Reprojection residual (2O,) f64 and cost = 0.5 r.r  (numpy: float cost; torch: 1-element tensor)."""
+    params, ci, pi, obs, mem = _ba_prepare(params, F, P, ci, pi, obs)
+    O = int(ci.shape[0])
+    if int(params.shape[0]) != 6 * F + 3 * P or int(pi.shape[0]) != O or int(obs.shape[0]) != O:
+        raise ValueError("ba_residual: inconsistent sizes")
+    Kh = _k_host(K)
+    if mem == VO_MEM_DEVICE:
+        import torch
+        r = torch.empty(2 * O, dtype=torch.float64, device=params.device)
+        cost = torch.empty(1, dtype=torch.float64, device=params.device)
+    else:
+        r = np.zeros(2 * O); cost = np.zeros(1)
+    check(ctx.lib.vo_ba_residual(ctx.handle, _ptr(params), F, P, _ptr(ci), _ptr(pi), _ptr(obs), O,
+                                 Kh.ctypes.data_as(_lib.c_f64p), _ptr(r), _ptr(cost), mem), "vo_ba_residual")
+    return r, (cost if mem == VO_MEM_DEVICE else float(cost[0]))
+
+
+def ba_normal_eq(ctx: Context, params, F: int, P: int, ci, pi, obs, K, obs_start: int = 0):
+    """Residual, cost and the normal equations -> dict(r, cost, Hcc, Hpp, Hcp, g)."""
+    params, ci, pi, obs, mem = _ba_prepare(params, F, P, ci, pi, obs)
+    O = int(ci.shape[0])
+    if int(params.shape[0]) != 6 * F + 3 * P or int(pi.shape[0]) != O or int(obs.shape[0]) != O:
+        raise ValueError("ba_normal_eq: inconsistent sizes")
+    Kh = _k_host(K)
+    if mem == VO_MEM_DEVICE:
+        import torch
+        mk = lambda *s: torch.empty(s, dtype=torch.float64, device=params.device)
+    else:
+        mk = lambda *s: np.zeros(s)
+    r, cost, Hcc, Hpp, Hcp, g = mk(2 * O), mk(1), mk(F, 6, 6), mk(P, 3, 3), mk(O, 6, 3), mk(6 * F + 3 * P)
+    check(ctx.lib.vo_ba_normal_eq(ctx.handle, _ptr(params), F, P, _ptr(ci), _ptr(pi), _ptr(obs), O,
+                                  Kh.ctypes.data_as(_lib.c_f64p), int(obs_start), _ptr(r), _ptr(cost), _ptr(Hcc),
+                                  _ptr(Hpp), _ptr(Hcp), _ptr(g), mem), "vo_ba_normal_eq")
+    return dict(r=r, cost=(cost if mem == VO_MEM_DEVICE else float(cost[0])), Hcc=Hcc, Hpp=Hpp, Hcp=Hcp, g=g)

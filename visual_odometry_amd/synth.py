@@ -55,3 +55,94 @@ def uniform_keypoints(shape, n, seed=0, margin=11):
     x = rng.uniform(margin, w - 1 - margin, n)
     y = rng.uniform(margin, h - 1 - margin, n)
     return np.stack([x, y], 1).astype(np.float32)
+
+
+def rodrigues(rv):
+    """Rotation vector -> matrix (float64)."""
+    rv = np.asarray(rv, np.float64)
+    th = np.linalg.norm(rv)
+    if th == 0:
+        return np.eye(3)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+
+def two_view_scene(n=3000, K=K_MALAGA, shape=MALAGA_SHAPE, inlier_frac=0.7, noise=0.3, seed=7):
+    """Seeded two-view scene -> dict(m1, m2 (n,2) f32, X (n,3) f32 world points, R, t, F_true, inlier mask)."""
+    rng = np.random.default_rng(seed)
+    Kd = K.astype(np.float64)
+    h, w = shape
+    # points sampled through camera 1's pixels at random depth -> all visible in image 1
+    uv = np.stack([rng.uniform(0, w - 1, n), rng.uniform(0, h - 1, n)], 1)
+    z = rng.uniform(6, 60, n)
+    X = (np.linalg.inv(Kd) @ np.hstack([uv, np.ones((n, 1))]).T).T * z[:, None]
+    R = rodrigues([0.01, -0.04, 0.008])
+    t = np.array([0.6, -0.05, 0.9])
+    x2 = (Kd @ (R @ X.T + t[:, None])).T
+    x2 = x2[:, :2] / x2[:, 2:]
+    inl = rng.uniform(size=n) < inlier_frac
+    m1 = uv + rng.normal(0, noise, uv.shape) * inl[:, None]
+    m2 = np.where(inl[:, None], x2 + rng.normal(0, noise, x2.shape),
+                  np.stack([rng.uniform(0, w - 1, n), rng.uniform(0, h - 1, n)], 1))
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(Kd)
+    F = Ki.T @ tx @ R @ Ki
+    return dict(m1=m1.astype(np.float32), m2=m2.astype(np.float32), X=X.astype(np.float32), R=R, t=t,
+                F=F / F[2, 2], inliers=inl, K=Kd)
+
+
+def fundamental_hypotheses(scene, H, seed=7):
+    """H seeded candidates: the true F, scaled and perturbed copies, and random matrices."""
+    rng = np.random.default_rng(seed)
+    F0 = scene["F"]
+    out = np.empty((H, 3, 3))
+    for h in range(H):
+        k = h % 4
+        if h == 0:
+            out[h] = F0
+        elif k == 0:
+            out[h] = F0 * rng.uniform(0.1, 10)
+        elif k == 1:
+            out[h] = F0 * (1 + rng.normal(0, 10 ** rng.uniform(-6, -2), (3, 3)))
+        elif k == 2:
+            out[h] = F0 + rng.normal(0, 1, (3, 3)) * np.abs(F0).max() * 10 ** rng.uniform(-5, -1)
+        else:
+            out[h] = rng.normal(0, 1, (3, 3))
+    return out
+
+
+def pose_hypotheses(scene, H, seed=7):
+    """H seeded [R|t] candidates around the true pose."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((H, 3, 4))
+    for h in range(H):
+        s = 0.0 if h == 0 else 10 ** rng.uniform(-6, -1)
+        R = rodrigues(rng.normal(0, s, 3)) @ scene["R"]
+        t = scene["t"] + rng.normal(0, s, 3)
+        out[h] = np.hstack([R, t[:, None]])
+    return out
+
+
+def ba_problem(F=10, P=5000, K=K_KITTI, visibility=1.0, seed=0, obs_noise=0.5):
+    """Seeded windowed-BA problem: points in front of cameras advancing along z.
+    -> dict(x (6F+3P) f64, ci, pi int64 (sorted by camera), obs (O,2) f32, K f64)."""
+    rng = np.random.default_rng(seed)
+    Kd = K.astype(np.float64)
+    pts = rng.uniform([-20, -3, 6], [20, 3, 60], (P, 3))
+    cams = np.zeros((F, 6))
+    cams[:, :3] = rng.normal(0, 0.01, (F, 3))
+    cams[:, 5] = -0.5 * np.arange(F)
+    ci, pi, obs = [], [], []
+    for f in range(F):
+        R = rodrigues(cams[f, :3])
+        Xc = pts @ R.T + cams[f, 3:]
+        uv = (Xc @ Kd.T)
+        uv = uv[:, :2] / uv[:, 2:]
+        vis = rng.uniform(size=P) < visibility
+        idx = np.nonzero(vis)[0]
+        ci.append(np.full(idx.size, f, np.int64)); pi.append(idx.astype(np.int64))
+        obs.append(uv[idx] + rng.normal(0, obs_noise, (idx.size, 2)))
+    x = np.hstack([(cams + rng.normal(0, 1e-3, cams.shape)).ravel(), (pts + rng.normal(0, 0.05, pts.shape)).ravel()])
+    return dict(x=x, ci=np.concatenate(ci), pi=np.concatenate(pi), obs=np.concatenate(obs).astype(np.float32), K=Kd,
+                F=F, P=P)
