@@ -139,6 +139,25 @@ int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, const int64
                     const int64_t *point_indices, const double *obs, int O, const double *K, int obs_start,
                     double *r, double *cost, double *Hcc, double *Hpp, double *Hcp, double *g, int mem);
 
+/* ---- Harris / Shi-Tomasi response, non-maximum suppression, top-K ------------
+ * vo_harris_response replaces cv.cornerHarris(float32(img), 2, 3, 0.1) in
+ * FeatureExtractor.harris (vo_pipeline/featureExtraction.py:37-40).  img: batch
+ * uint8 images; R: (batch, height, width) float32, tight.  mode 0 = Harris
+ * (a*c - b*b - k*(a+c)^2), mode 1 = min eigenvalue (Shi-Tomasi), the quantity the
+ * tracker thresholds (minEigThreshold, vo_pipeline/poseEstimation.py:129).
+ */
+int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
+                       int64_t img_stride, int block_size, int ksize, float k, int mode, float *R, int mem);
+/* vo_nms_topk stands in for the dilate / threshold(0.01*max) / connected-component
+ * centroid steps of FeatureExtractor.harris (vo_pipeline/featureExtraction.py:41-50):
+ * it keeps local maxima of R above rel_thresh*max(R) within a (2*radius+1)^2 window
+ * (ties: earlier raster index) and returns the K strongest per image, strongest
+ * first.  xy: (batch, K, 2) float32 (x, y), zero-filled past count[b]; scores:
+ * (batch, K) float32 or NULL; count: (batch) int32.  K <= 4096.
+ */
+int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, int width, float rel_thresh, int radius,
+                int K, float *xy, float *scores, int32_t *count, int mem);
+
 #ifdef __cplusplus
 }
 #endif

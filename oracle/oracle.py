@@ -31,6 +31,7 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _declare(_lib)
         _declare_more(_lib)
+        _declare_harris(_lib)
     return _lib
 
 
@@ -70,6 +71,13 @@ def _declare_more(L):
     L.vo_or_ba_normal_eq.restype = ctypes.c_double
     L.vo_or_ba_normal_eq.argtypes = [_f64p, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _f64p, ctypes.c_int, _f64p,
                                      ctypes.c_int, _f64p, _f64p, _f64p, _f64p, _f64p]
+
+
+def _declare_harris(L):
+    L.vo_or_harris_response.restype = None
+    L.vo_or_harris_response.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _f32p]
+    L.vo_or_nms_topk.restype = ctypes.c_int
+    L.vo_or_nms_topk.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _f32p, _f32p]
 
 
 def _p(a, t):
@@ -192,3 +200,19 @@ def ba_normal_eq(params, F, P, ci, pi, obs, K, obs_start=0):
                                     _p(K, _f64p), int(obs_start), _p(r, _f64p), _p(Hcc, _f64p), _p(Hpp, _f64p),
                                     _p(Hcp, _f64p), _p(g, _f64p))
     return dict(r=r, cost=cost, Hcc=Hcc, Hpp=Hpp, Hcp=Hcp, g=g)
+
+
+def harris_response(img, k=0.1, mode=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    R = np.zeros((h, w), np.float32)
+    lib().vo_or_harris_response(_p(img, _u8p), w, h, w, float(k), int(mode), _p(R, _f32p))
+    return R
+
+
+def nms_topk(R, K, rel_thresh=0.01, radius=1):
+    R = np.ascontiguousarray(R, np.float32)
+    h, w = R.shape
+    xy = np.zeros((K, 2), np.float32); sc = np.zeros(K, np.float32)
+    m = lib().vo_or_nms_topk(_p(R, _f32p), w, h, float(rel_thresh), int(radius), int(K), _p(xy, _f32p), _p(sc, _f32p))
+    return xy, sc, m

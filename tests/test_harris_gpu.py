@@ -1,0 +1,71 @@
+"""GPU parity of the Harris / Shi-Tomasi response (bit-exact float32) and of the
+NMS + top-K selection (identical corner lists) against the CPU oracle."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (8, 32), (9, 33), (60, 83), (376, 1241), (480, 640)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_response_bit_exact(oracle, ctx, shape, mode):
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (2,) + shape, dtype=np.uint8)
+    if shape[0] > 50:
+        imgs[1] = synth.frame_pair(shape, seed=4)[0]
+    R = hip.harris_response(ctx, imgs, 0.1, mode)
+    for b in range(2):
+        np.testing.assert_array_equal(R[b], oracle.harris_response(imgs[b], 0.1, mode))
+
+
+@pytest.mark.parametrize("shape,K,radius", [((60, 83), 50, 1), ((376, 1241), 2000, 5), ((376, 1241), 4096, 1),
+                                           ((480, 640), 300, 8), ((40, 40), 4096, 1)])
+def test_nms_topk_identical(oracle, ctx, shape, K, radius):
+    from visual_odometry_amd import hip
+    imgs = np.stack([synth.frame_pair(shape, seed=s)[0] for s in (1, 2)])
+    R = hip.harris_response(ctx, imgs, 0.04, hip.MIN_EIGEN)
+    xy, sc, cnt = hip.nms_topk(ctx, R, K, 0.01, radius)
+    for b in range(2):
+        rxy, rsc, m = oracle.nms_topk(R[b], K, 0.01, radius)
+        assert cnt[b] == m and m > 0
+        np.testing.assert_array_equal(xy[b], rxy)
+        np.testing.assert_array_equal(sc[b], rsc)
+
+
+def test_nms_ties_and_flat(oracle, ctx):
+    from visual_odometry_amd import hip
+    R = np.zeros((1, 20, 30), np.float32)
+    R[0, 5, 5] = 10; R[0, 5, 6] = 10; R[0, 10, 20] = 7; R[0, 11, 21] = 8; R[0, 18, 28] = 3
+    xy, sc, cnt = hip.nms_topk(ctx, R, 8, 0.01, 1)
+    rxy, rsc, m = oracle.nms_topk(R[0], 8, 0.01, 1)
+    assert cnt[0] == m == 3
+    np.testing.assert_array_equal(xy[0], rxy)
+    flat = np.zeros((1, 16, 16), np.float32)
+    xy, sc, cnt = hip.nms_topk(ctx, flat, 4, 0.01, 1)
+    assert cnt[0] == 0 and (xy == 0).all()
+
+
+def test_harris_device_path_feeds_tracker(oracle, ctx):
+    """Device buffers end to end: response -> top-2000 corners -> pyramidal LK."""
+    import torch
+    from visual_odometry_amd import hip
+    img0, img1, A = synth.frame_pair(synth.KITTI_SHAPE, seed=2021)
+    t0, t1 = torch.from_numpy(img0).cuda(), torch.from_numpy(img1).cuda()
+    R = hip.harris_response(ctx, t0, 0.04, hip.MIN_EIGEN)
+    xy, sc, cnt = hip.nms_topk(ctx, R, 2000, 0.01, 5)
+    ctx.sync()
+    assert int(cnt[0]) == 2000
+    rxy, _, m = oracle.nms_topk(oracle.harris_response(img0, 0.04, 1), 2000, 0.01, 5)
+    np.testing.assert_array_equal(xy[0].cpu().numpy(), rxy)
+    p0 = hip.Pyramid(ctx, 1, *synth.KITTI_SHAPE).build(t0); p1 = hip.Pyramid(ctx, 1, *synth.KITTI_SHAPE).build(t1)
+    out, st, err = hip.klt_track(ctx, p0, p1, xy)
+    ctx.sync()
+    ro, rs, _ = oracle.klt(img0, img1, rxy)
+    assert (st[0].cpu().numpy() == rs.ravel()).mean() >= 0.995
+    ok = rs.ravel() == 1
+    assert np.abs(out[0].cpu().numpy()[ok] - ro[ok]).max() <= 0.05
+    truth = rxy @ A[:, :2].T + A[:, 2]
+    assert np.median(np.linalg.norm(ro[ok] - truth[ok], axis=1)) < 0.05

@@ -1,0 +1,60 @@
+"""CPU tests of the Harris/NMS oracle against independent scipy.ndimage arithmetic
+(mode='mirror' == BORDER_REFLECT_101).  cv2 is absent: parity with OpenCV itself is unpinned."""
+import numpy as np
+from scipy import ndimage
+
+from visual_odometry_amd import synth
+
+
+def _independent_response(img, k=0.1):
+    a = img.astype(np.float64)
+    sm, df = np.array([1, 2, 1]) / 8.0, np.array([-1, 0, 1.0])
+    dx = ndimage.correlate1d(ndimage.correlate1d(a, df, axis=1, mode="mirror"), sm, axis=0, mode="mirror")
+    dy = ndimage.correlate1d(ndimage.correlate1d(a, sm, axis=1, mode="mirror"), df, axis=0, mode="mirror")
+
+    def box(m):  # offsets {-1, 0} in both axes, mirror border on the product map
+        p = np.pad(m, ((1, 0), (1, 0)), mode="reflect")
+        return p[1:, 1:] + p[1:, :-1] + p[:-1, 1:] + p[:-1, :-1]
+    A, B, C = box(dx * dx), box(dx * dy), box(dy * dy)
+    return A, B, C
+
+
+def test_harris_response_vs_ndimage(oracle):
+    img, _, _ = synth.frame_pair((60, 83), seed=3)
+    A, B, C = _independent_response(img)
+    R = oracle.harris_response(img, 0.1, 0)
+    # the structure tensor is exact in float32 for 8-bit input; the response is float32 arithmetic
+    a, b, c = A.astype(np.float32), B.astype(np.float32), C.astype(np.float32)
+    assert (a == A).all() and (b == B).all() and (c == C).all()
+    ref = (a * c - b * b) - (np.float32(0.1) * (a + c)) * (a + c)
+    np.testing.assert_array_equal(R, ref)
+    Rm = oracle.harris_response(img, 0.1, 1)
+    refm = (a * np.float32(0.5) + c * np.float32(0.5)) - np.sqrt(
+        (a * np.float32(0.5) - c * np.float32(0.5)) ** 2 + b * b, dtype=np.float32)
+    np.testing.assert_array_equal(Rm, refm)
+
+
+def test_nms_topk_rule(oracle):
+    R = np.zeros((20, 30), np.float32)
+    R[5, 5] = 10; R[5, 6] = 10          # tie: the earlier raster index wins
+    R[10, 20] = 7; R[11, 21] = 8        # neighbours: only the larger survives
+    R[15, 3] = 0.05                     # below 0.01 * max? 0.05 < 0.1 -> rejected
+    R[18, 28] = 3
+    xy, sc, m = oracle.nms_topk(R, 8, 0.01, 1)
+    assert m == 3
+    np.testing.assert_array_equal(xy[:3], [[5, 5], [21, 11], [28, 18]])
+    np.testing.assert_array_equal(sc[:3], [10, 8, 3])
+    assert (xy[3:] == 0).all()
+    xy2, _, m2 = oracle.nms_topk(R, 2, 0.01, 1)
+    assert m2 == 2 and (xy2 == xy[:2]).all()
+
+
+def test_harris_finds_planted_corners(oracle):
+    img = np.full((80, 100), 40, np.uint8)
+    img[20:50, 30:70] = 200               # bright rectangle -> 4 corners
+    R = oracle.harris_response(img, 0.04, 0)
+    xy, sc, m = oracle.nms_topk(R, 4, 0.01, 3)
+    assert m == 4
+    corners = {(30, 20), (69, 20), (30, 49), (69, 49)}
+    for x, y in xy:
+        assert min(abs(x - cx) + abs(y - cy) for cx, cy in corners) <= 2

@@ -49,6 +49,11 @@ SIGNATURES = {
                                       c_vp, c_vp, ctypes.c_int]),
     "vo_ba_normal_eq": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_f64p,
                                        ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_harris_response": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                          c_vp, ctypes.c_int]),
+    "vo_nms_topk": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                   ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int]),
 }
 
 _lib = None

@@ -287,3 +287,53 @@ def ba_normal_eq(ctx: Context, params, F: int, P: int, ci, pi, obs, K, obs_start
                                   Kh.ctypes.data_as(_lib.c_f64p), int(obs_start), _ptr(r), _ptr(cost), _ptr(Hcc),
                                   _ptr(Hpp), _ptr(Hcp), _ptr(g), mem), "vo_ba_normal_eq")
     return dict(r=r, cost=(cost if mem == VO_MEM_DEVICE else float(cost[0])), Hcc=Hcc, Hpp=Hpp, Hcp=Hcp, g=g)
+
+
+HARRIS = 0
+MIN_EIGEN = 1
+
+
+def harris_response(ctx: Context, imgs, k: float = 0.1, mode: int = HARRIS):
+    """Corner response (B,H,W) float32 of uint8 images (H,W) or (B,H,W)."""
+    if _is_torch(imgs):
+        import torch
+        t = imgs if imgs.dim() == 3 else imgs.unsqueeze(0)
+        assert t.dtype == torch.uint8 and t.is_cuda
+        if t.stride(2) != 1:
+            t = t.contiguous()
+        B, H, W = t.shape
+        R = torch.empty((B, H, W), dtype=torch.float32, device=t.device)
+        check(ctx.lib.vo_harris_response(ctx.handle, _ptr(t), B, H, W, t.stride(1), t.stride(0) if B > 1 else t.stride(1) * H,
+                                         2, 3, float(k), int(mode), _ptr(R), VO_MEM_DEVICE), "vo_harris_response")
+        return R
+    a = np.ascontiguousarray(imgs, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[None]
+    B, H, W = a.shape
+    R = np.zeros((B, H, W), np.float32)
+    check(ctx.lib.vo_harris_response(ctx.handle, _ptr(a), B, H, W, a.strides[1], a.strides[0], 2, 3, float(k), int(mode),
+                                     _ptr(R), VO_MEM_HOST), "vo_harris_response")
+    return R
+
+
+def nms_topk(ctx: Context, R, K: int, rel_thresh: float = 0.01, radius: int = 1):
+    """Strongest K local maxima per image -> (xy (B,K,2) f32, scores (B,K) f32, count (B,) i32)."""
+    if _is_torch(R):
+        import torch
+        t = R if R.dim() == 3 else R.unsqueeze(0)
+        assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()
+        B, H, W = t.shape
+        xy = torch.empty((B, K, 2), dtype=torch.float32, device=t.device)
+        sc = torch.empty((B, K), dtype=torch.float32, device=t.device)
+        cnt = torch.empty(B, dtype=torch.int32, device=t.device)
+        mem = VO_MEM_DEVICE
+    else:
+        t = np.ascontiguousarray(R, dtype=np.float32)
+        if t.ndim == 2:
+            t = t[None]
+        B, H, W = t.shape
+        xy = np.zeros((B, K, 2), np.float32); sc = np.zeros((B, K), np.float32); cnt = np.zeros(B, np.int32)
+        mem = VO_MEM_HOST
+    check(ctx.lib.vo_nms_topk(ctx.handle, _ptr(t), B, H, W, float(rel_thresh), int(radius), int(K), _ptr(xy), _ptr(sc),
+                              _ptr(cnt), mem), "vo_nms_topk")
+    return xy, sc, cnt
