@@ -1,6 +1,22 @@
 // Context, error reporting, staging buffers and stream timers of libvo_hip.
 #include "vo_internal.h"
+#include <mutex>
 #include <new>
+#include <unordered_set>
+
+// Live contexts: objects that outlive their context (pyramids destroyed at
+// interpreter shutdown in arbitrary order) must not touch a freed vo_ctx.
+static std::mutex g_live_mu;
+static std::unordered_set<const vo_ctx *> &live_set()
+{
+    static auto *s = new std::unordered_set<const vo_ctx *>();  // never destroyed: safe during process exit
+    return *s;
+}
+bool vo_ctx_is_live(const vo_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return live_set().count(ctx) != 0;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -34,6 +50,10 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
     c->stream = (hipStream_t)stream;
     VO_HIP_CHECK(hipEventCreate(&c->ev0));
     VO_HIP_CHECK(hipEventCreate(&c->ev1));
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        live_set().insert(c);
+    }
     *out = c;
     return VO_OK;
 }
@@ -41,6 +61,10 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
 extern "C" int vo_ctx_destroy(vo_ctx *ctx)
 {
     if (!ctx) return VO_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!live_set().erase(ctx)) return VO_OK;  // already destroyed
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->stage)

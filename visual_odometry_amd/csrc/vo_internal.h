@@ -41,6 +41,8 @@ struct vo_ctx {
     vo_devbuf stage[8];
 };
 
+bool vo_ctx_is_live(const vo_ctx *ctx);
+
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
 

@@ -130,8 +130,10 @@ extern "C" int vo_pyr_create(vo_ctx *ctx, int batch, int height, int width, int 
 extern "C" int vo_pyr_destroy(vo_pyr *pyr)
 {
     if (!pyr) return VO_OK;
-    (void)hipSetDevice(pyr->ctx->device);
-    (void)hipStreamSynchronize(pyr->ctx->stream);
+    if (vo_ctx_is_live(pyr->ctx)) {
+        (void)hipSetDevice(pyr->ctx->device);
+        (void)hipStreamSynchronize(pyr->ctx->stream);
+    }
     if (pyr->pool) (void)hipFree(pyr->pool);
     if (pyr->own0) (void)hipFree(pyr->own0);
     delete pyr;

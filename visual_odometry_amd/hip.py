@@ -4,7 +4,10 @@ Arrays may be numpy (host memory: the library stages and synchronises) or torch
 tensors on the context's GPU (raw device pointers: asynchronous on the stream).
 torch is used as a buffer provider only.
 """
+import atexit
 import ctypes
+import sys
+import weakref
 from typing import Optional, Tuple
 
 import numpy as np
@@ -34,6 +37,7 @@ class Context:
         check(self.lib.vo_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)), "vo_ctx_create")
         self.handle = h
         self.device = int(device)
+        _live_objects.add(self)
 
     @classmethod
     def from_torch(cls, device: int = 0) -> "Context":
@@ -58,13 +62,31 @@ class Context:
             self.handle = None
 
     def __del__(self):
+        # at interpreter shutdown the ordered atexit hook below has already run
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
             pass
 
 
+_live_objects = weakref.WeakSet()
 _default_ctx = {}
+
+
+@atexit.register
+def _shutdown():
+    """Destroy pyramids before contexts, while the HIP runtime is still up."""
+    objs = list(_live_objects)
+    for o in objs:
+        if isinstance(o, Pyramid):
+            o.close()
+    for o in objs:
+        if isinstance(o, Context):
+            o.close()
+    _default_ctx.clear()
+
 
 
 def default_context(device: int = 0) -> Context:
@@ -85,6 +107,7 @@ class Pyramid:
         self.handle = h
         self.max_level = ctx.lib.vo_pyr_max_level(h)
         self._keep = None
+        _live_objects.add(self)
 
     def level_shape(self, level: int) -> Tuple[int, int]:
         hh, ww, pp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
@@ -130,6 +153,8 @@ class Pyramid:
             self._keep = None
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -1,0 +1,87 @@
+"""PoseEstimation -- KLT tracking and PnP-RANSAC wrappers with the reference's API
+(vo_pipeline/poseEstimation.py:18-133); the cv2 calls are replaced by libvo_hip."""
+import enum
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .. import hip, params
+from . import _runtime, ransac
+from .trackPoints import TrackPoints
+
+
+class AlgoMethod(enum.Enum):
+    DEFAULT = 0,
+    P3P = 1,
+    AP3P = 2,
+
+
+class PoseEstimation:
+    def __init__(self,
+                 K: np.ndarray,
+                 first_kps: Optional[np.ndarray] = None,
+                 use_KLT: bool = True,
+                 algo_method_type: AlgoMethod = AlgoMethod.DEFAULT):
+        self.K = K
+        self.prev_kpts = first_kps
+        self.algo_method_type = algo_method_type
+        self.algo_method = None
+        self.get_method()
+        self.use_KLT = use_KLT
+        self.KLT_tracker = TrackPoints(params.KLT_RADIUS, params.KLT_N_ITERS, params.KLT_LAMBDA)
+
+    def get_method(self):
+        # every method funnels into the same minimal solver (P3P on 3 points + 1 to disambiguate)
+        self.algo_method = {AlgoMethod.DEFAULT: "ITERATIVE", AlgoMethod.P3P: "P3P",
+                            AlgoMethod.AP3P: "AP3P"}[self.algo_method_type]
+
+    def update_prev_kpts(self, kps: np.ndarray) -> None:
+        self.prev_kpts = kps
+
+    def PnP(self, pointcloud: np.ndarray, img_key_points: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """
+        :param pointcloud:      (N, 3) landmarks matched to the keypoints
+        :param img_key_points:  (N, 2) keypoints in the current image
+        :return                 (M (4,4) float64 world->camera, inliers (k,1) int32)
+        """
+        assert pointcloud.shape[0] == img_key_points.shape[0]
+        success, R, t, inliers = ransac.solve_pnp_ransac(
+            pointcloud, img_key_points, self.K,
+            thr=params.PNP_RANSAC_REPROJ_THRESHOLD,
+            conf=params.PNP_RANSAC_CONFIDENCE,
+            max_iters=params.PNP_RANSAC_MAX_ITERS)
+        assert success, "PNP RANSAC was not able to compute a pose from 2D - 3D correspondences"
+        M = np.eye(4)
+        M[0:3, 0:3] = R
+        M[0:3, 3] = np.ravel(t)
+        return M, inliers
+
+    def match_key_points(self, pointcloud: np.ndarray, img0: np.ndarray, img1: np.ndarray) -> np.ndarray:
+        """Track self.prev_kpts from img0 to img1 and keep the found ones (the descriptor
+        branch of the reference, use_KLT=False, needs SIFT and is not part of this build)."""
+        if not self.use_KLT:
+            raise NotImplementedError("descriptor matching is outside the GPU front end; construct with use_KLT=True")
+        pts1, st = self.KLT(img0, img1, self.prev_kpts)
+        found = st == 1
+        pts1 = pts1[found[:, 0]]
+        self.update_prev_kpts(pts1)
+        return pts1
+
+    @staticmethod
+    def KLT(img0: np.ndarray, img1: np.ndarray, prev_kpts: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Pyramidal LK from img0 to img1 -> (tracked_pts (N,2) float32, status (N,1) uint8)."""
+        img0 = np.ascontiguousarray(img0, dtype=np.uint8)
+        img1 = np.ascontiguousarray(img1, dtype=np.uint8)
+        if img0.ndim != 2 or img0.shape != img1.shape:
+            raise ValueError("KLT: img0 and img1 must be grayscale images of one size")
+        pts = np.float32(prev_kpts).reshape(-1, 2)
+        n = pts.shape[0]
+        if n == 0:
+            return np.zeros((0, 2), np.float32), np.zeros((0, 1), np.uint8)
+        ctx = _runtime.context()
+        p0, p1 = _runtime.pyramid_pair(img0.shape[0], img0.shape[1], params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS)
+        p0.build(img0)
+        p1.build(img1)
+        out, st, _ = hip.klt_track(ctx, p0, p1, pts, max_iters=params.KLT_N_ITERS, eps=0.001,
+                                   min_eig=params.KLT_MIN_EIGEN_THRESHOLD)
+        return out[0], st[0].reshape(n, 1)
