@@ -46,17 +46,20 @@ def algorithmic_bytes(max_level, n_kp):
     return pyramid + tracker, tracker
 
 
-def make_streams(n_streams, ring, seed0):
+def make_streams(stream_ids, ring, base_seed=2021):
     """Per stream a ring of `ring` frames (texture seen through successive small
-    warps) and a seeded keypoint set."""
+    warps) and a seeded keypoint set; a stream's data depends on its global id only."""
     from scipy import ndimage
     from visual_odometry_amd import synth
+    from visual_odometry_amd import streams
+    n_streams = len(stream_ids)
     frames = np.empty((ring, n_streams, H, W), np.uint8)
     pts = np.empty((n_streams, N_KP, 2), np.float32)
     margin = 40
     ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
-    for s in range(n_streams):
-        rng = np.random.default_rng(seed0 + s)
+    for s, sid in enumerate(stream_ids):
+        seed = streams.stream_seed(base_seed, sid)
+        rng = np.random.default_rng(seed)
         tex = synth.texture((H, W), rng, margin)
         off = np.zeros(2)
         for r in range(ring):
@@ -70,7 +73,7 @@ def make_streams(n_streams, ring, seed0):
             img = ndimage.map_coordinates(tex, [sy, sx], order=1, mode="nearest")
             img = img + rng.normal(0, 1.0, img.shape)
             frames[r, s] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
-        pts[s] = synth.uniform_keypoints((H, W), N_KP, seed=seed0 + s, margin=11)
+        pts[s] = synth.uniform_keypoints((H, W), N_KP, seed=seed, margin=11)
     return frames, pts
 
 
@@ -103,7 +106,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from visual_odometry_amd import hip
+    from visual_odometry_amd import hip, streams
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,7 +119,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     S, R = args.streams_per_gpu, args.ring
-    frames_h, pts_h = make_streams(S, R, seed0=2021 + 1000 * rank)
+    owned = streams.shard_streams(S * world, rank, world)      # weak scaling: S streams per GPU
+    frames_h, pts_h = make_streams(owned, R)
     frames = torch.from_numpy(frames_h).to(dev)          # (R, S, H, W) resident in HBM
     pts = torch.from_numpy(pts_h).to(dev)
     ctx = hip.Context.from_torch(local_rank)
@@ -153,17 +157,11 @@ def main():
         step(evs[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = streams.max_over_ranks(elapsed, dev, world)
 
     klt_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     tracked = out[1].sum(dim=1).to(torch.int32)           # per-stream tracked keypoints of the last step
-    if world > 1:                                         # the only data exchange: a final gather
-        gathered = [torch.empty_like(tracked) for _ in range(world)]
-        dist.all_gather(gathered, tracked)
-        tracked = torch.cat(gathered)
+    tracked = streams.gather_per_stream(tracked, owned, S * world, world)   # the only data exchange: a final gather
     tracked_frac = float(tracked.float().mean().item()) / N_KP
 
     if rank == 0:
