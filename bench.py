@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=64)
     ap.add_argument("--ring", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="development aid: synthesise only this many distinct streams and repeat them (0 = all distinct)")
     args = ap.parse_args()
 
     import torch
@@ -120,7 +122,13 @@ def main():
 
     S, R = args.streams_per_gpu, args.ring
     owned = streams.shard_streams(S * world, rank, world)      # weak scaling: S streams per GPU
-    frames_h, pts_h = make_streams(owned, R)
+    if args.distinct and args.distinct < S:
+        f0, p0 = make_streams(owned[:args.distinct], R)
+        rep = (S + args.distinct - 1) // args.distinct
+        frames_h = np.tile(f0, (1, rep, 1, 1))[:, :S].copy()
+        pts_h = np.tile(p0, (rep, 1, 1))[:S].copy()
+    else:
+        frames_h, pts_h = make_streams(owned, R)
     frames = torch.from_numpy(frames_h).to(dev)          # (R, S, H, W) resident in HBM
     pts = torch.from_numpy(pts_h).to(dev)
     ctx = hip.Context.from_torch(local_rank)
@@ -187,6 +195,7 @@ def main():
             "config": {"workload": "KITTI-shaped 1241x376 u8 frames, 2000 keypoints/frame, 4-level pyramid "
                                    "(maxLevel=3), win 21, 10 iters, eps 1e-3, minEig 1e-2",
                        "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R,
+                       "distinct_streams": (args.distinct if args.distinct and args.distinct < S else S) * world,
                        "tracked_fraction": tracked_frac, "parallelism": f"stream-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "klt_track_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -116,6 +116,11 @@ void vo_or_scharr(const uint8_t *src, int w, int h, int stride, int16_t *dst)
     free(t1);
 }
 
+/* diagnostic counters of the last vo_or_klt call: Gauss-Newton iterations and
+ * (keypoint, level) pairs that reached the iteration loop */
+static long g_iters, g_levels;
+void vo_or_klt_stats(long *iters, long *levels) { *iters = g_iters; *levels = g_levels; }
+
 typedef struct {
     int w, h;
     uint8_t *img;   /* h*w */
@@ -199,6 +204,7 @@ int vo_or_klt(const uint8_t *img0, const uint8_t *img1, int w, int h, int stride
     int16_t *dIw = Iw + (size_t)win * win;
 
     for (int i = 0; i < n; ++i) { status[i] = 1; if (err) err[i] = 0.f; }
+    g_iters = 0; g_levels = 0;
 
     for (int level = maxL; level >= 0; --level) {
         const or_level *I = &P[level], *J = &Q[level];
@@ -254,7 +260,9 @@ int vo_or_klt(const uint8_t *img0, const uint8_t *img1, int w, int h, int stride
             D = 1.f / D;
             nx -= half; ny -= half;
             float pdx = 0, pdy = 0;
+            ++g_levels;
             for (int j = 0; j < max_iters; ++j) {
+                ++g_iters;
                 int inx = cv_floor(nx), iny = cv_floor(ny);
                 if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
                     if (level == 0) status[p] = 0;

@@ -9,33 +9,35 @@
 // Mapping: lane l < 63 owns window column l % 21 and the 7 rows 7*(l / 21)...;
 // its template values (I, Ix, Iy) stay in registers for the whole level.
 // Per wave the kernel stages in LDS
-//   * the 24x24 previous-image tile (as 16-bit pixel pairs {p[x], p[x+1]} ready
-//     for v_dot2_u32_u16 against the packed bilinear weights),
-//   * the 22x22 Scharr tile computed from it, and
+//   * the 24x24 previous-image tile as 16-bit pixel pairs {p[x], p[x+1]} (ready
+//     for v_dot2_u32_u16 against the packed bilinear weights); the Scharr
+//     derivatives are formed from it in registers with packed 16-bit math, two
+//     window columns per instruction, and never touch memory;
 //   * a (22+2M)x(21+2M) tile of the next image around the current estimate,
 //     re-staged only when the estimate leaves the M-pixel margin.
-// Row strides are chosen so that the three 7-row strips of a half-wave hit
-// disjoint LDS banks.  The 2x2 system and the right-hand side are reduced over
-// the wave with DPP adds; every branch is wave-uniform.
+// The row stride (35 dwords) puts the three 7-row strips of a half-wave on
+// disjoint LDS banks.  Per-lane sums are exact int32 (v_mad_i32_i24); the 2x2
+// system and the right-hand side are reduced over the wave with DPP adds; every
+// branch is wave-uniform.
 #include "vo_internal.h"
 
 #define KLT_WIN 21
 #define KLT_HALF 10.0f
-#define KLT_M 4                         // margin of the next-image tile (pixels)
+#define KLT_M 3                         // margin of the next-image tile (pixels)
 #define JT_S 35                         // next-image tile row stride (dwords), 7*35 % 32 == 21
 #define JT_ROWS (KLT_WIN + 1 + 2 * KLT_M)
 #define JT_COLS (KLT_WIN + 2 * KLT_M)   // pair columns
-#define PT_S 26                         // previous-image pair tile stride (dwords)
+#define PT_S 35                         // previous-image pair tile stride (dwords), 7*35 % 32 == 21
 #define PT_ROWS 24
-#define DT_S 26                         // derivative tile stride (dwords)
-#define DT_ROWS 22
-#define LDS_A_DWORDS (JT_S * JT_ROWS)   // region A: previous tile, later next-image tile
-#define LDS_B_DWORDS (DT_S * DT_ROWS)   // region B: derivative tile
-#define LDS_WAVE_DWORDS (((LDS_A_DWORDS + LDS_B_DWORDS) + 3) / 4 * 4)
+#define LDS_A_DWORDS (JT_S * JT_ROWS)   // one region per wave: previous-image tile, later next-image tile
+#define LDS_WAVE_DWORDS ((LDS_A_DWORDS + 3) / 4 * 4)
 #define KLT_WAVES 4
 
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef short v2i16 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct KltLevel {
     const uint8_t *prev;
@@ -58,6 +60,7 @@ struct KltArgs {
     float *err;
     int max_iters;
     double eps2;
+    float eps2_lo, eps2_hi;  // float brackets of eps2: outside them the float test decides
     float min_eig;
 };
 
@@ -110,23 +113,45 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
 // (x0, y0); pixels outside the image follow BORDER_REFLECT_101.
+// Interior tiles: one unaligned 4-byte read yields three pairs (v_perm_b32).
 template <int ROWS, int PAIRS, int STRIDE>
 __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
                                             int x0, int y0, int lane)
 {
-    constexpr int GROUPS = (PAIRS + 2) / 3;  // 3 pairs from one 4-byte read
-    const bool inside = (x0 >= 0) && (y0 >= 0) && (x0 + 3 * GROUPS + 1 <= w) && (y0 + ROWS <= h);
+    constexpr int GROUPS = (PAIRS + 2) / 3;
+    constexpr int ITEMS = ROWS * GROUPS;
+    constexpr int ROUNDS = (ITEMS + 63) / 64;
+    static_assert(3 * GROUPS <= STRIDE, "tile row too narrow");
+    static_assert(ITEMS <= 512, "index arithmetic below assumes a small tile");
+    // rows are reflected per item, so only the column range has to lie inside the image
+    const bool inside = (x0 >= 0) && (x0 + 3 * GROUPS + 1 <= w);
     if (inside) {
-        const uint8_t *base = img + (int64_t)y0 * pitch + x0;
-        for (int idx = lane; idx < ROWS * GROUPS; idx += 64) {
-            int r = idx / GROUPS, g = idx - r * GROUPS;
-            uint32_t q;
-            __builtin_memcpy(&q, base + (int64_t)r * pitch + 3 * g, 4);
-            uint32_t p0 = q & 0xff, p1 = (q >> 8) & 0xff, p2 = (q >> 16) & 0xff, p3 = q >> 24;
-            uint32_t *d = lds + r * STRIDE + 3 * g;
-            d[0] = p0 | (p1 << 16);
-            if (3 * g + 1 < STRIDE) d[1] = p1 | (p2 << 16);
-            if (3 * g + 2 < STRIDE) d[2] = p2 | (p3 << 16);
+        const uint8_t *base = img + x0;
+        const int pitch32 = (int)pitch;
+        uint32_t q[ROUNDS];
+        int dst[ROUNDS];
+        // keep the per-lane item coordinates from being hoisted out of the level
+        // loop (they would stay live in ~16 registers for the whole kernel)
+        int l = lane;
+        asm volatile("" : "+v"(l));
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            int idx = l + 64 * k;
+            if (ITEMS % 64 != 0 && k == ROUNDS - 1) idx = min(idx, ITEMS - 1);  // tail lanes repeat the last item
+            // idx < 512: exact division by a small constant with one 24-bit multiply
+            constexpr unsigned RCP = (1u << 16) / GROUPS + 1;
+            const unsigned r = __umul24((unsigned)idx, RCP) >> 16;
+            const unsigned g3 = 3u * ((unsigned)idx - r * GROUPS);
+            const unsigned y = (unsigned)refl(y0 + (int)r, h);
+            __builtin_memcpy(&q[k], base + (__umul24(y, (unsigned)pitch32) + g3), 4);
+            dst[k] = (int)(__umul24(r, (unsigned)STRIDE) + g3);
+        }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            uint32_t *d = lds + dst[k];
+            d[0] = __builtin_amdgcn_perm(0u, q[k], 0x0c010c00u);
+            d[1] = __builtin_amdgcn_perm(0u, q[k], 0x0c020c01u);
+            d[2] = __builtin_amdgcn_perm(0u, q[k], 0x0c030c02u);
         }
     } else {
         for (int idx = lane; idx < ROWS * PAIRS; idx += 64) {
@@ -162,7 +187,6 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
     const int64_t pidx = (int64_t)img * A.n + kp;
 
     uint32_t *ldsA = lds_all + wid * LDS_WAVE_DWORDS;
-    uint32_t *ldsB = ldsA + LDS_A_DWORDS;
 
     // lane -> window column and 7-row strip; lane 63 shadows lane 0 with zero weight
     const bool active = lane < 63;
@@ -170,6 +194,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
     const int col = wl % KLT_WIN;
     const int row0 = (wl / KLT_WIN) * 7;
 
+    const int lane_jt = row0 * JT_S + col;
     const float px0 = A.prev_pts[2 * pidx], py0 = A.prev_pts[2 * pidx + 1];
     float outx = 0.f, outy = 0.f;
     int status = 1;
@@ -205,56 +230,69 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
         uint32_t wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
         uint32_t wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
 
-        // ---- template: previous-image tile, Scharr tile, bilinear samples ----
+        // ---- template: previous-image tile -> Scharr pairs in registers -> bilinear samples ----
         wave_sync();  // region A may still be read as the coarser level's next-image tile
         stage_pairs<PT_ROWS, 23, PT_S>(ldsA, pimg, L.ppitch, L.w, L.h, ipx - 1, ipy - 1, lane);
         wave_sync();
-        for (int idx = lane; idx < DT_ROWS * 22; idx += 64) {
-            int y = idx / 22, x = idx - y * 22;
-            const uint32_t *t = ldsA + y * PT_S + x;
-            uint32_t q00 = t[0], q01 = t[1];
-            uint32_t q10 = t[PT_S], q11 = t[PT_S + 1];
-            uint32_t q20 = t[2 * PT_S], q21 = t[2 * PT_S + 1];
-            int a0 = q00 & 0xffff, a1 = q00 >> 16, a2 = q01 >> 16;
-            int b0 = q10 & 0xffff, b2 = q11 >> 16;
-            int c0 = q20 & 0xffff, c1 = q20 >> 16, c2 = q21 >> 16;
-            int dx = 3 * (a2 - a0) + 10 * (b2 - b0) + 3 * (c2 - c0);
-            int dy = 3 * (c0 - a0) + 10 * (c1 - a1) + 3 * (c2 - a2);
-            // the derivative image is zero outside the image
-            int gx = ipx + x, gy = ipy + y;
-            bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
-            ldsB[y * DT_S + x] = in ? (((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16)) : 0u;
-        }
-        wave_sync();
-
-        float Iv[7], Ixv[7], Iyv[7];
-        float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
+        int Ii[7];
+        v2f Ixy[7];      // template derivatives (Ix, Iy) as float pairs for packed FMAs
+        v2f s12 = {0.f, 0.f};
+        float sA22 = 0.f;
+        // lane 63 shadows lane 0: zero derivative weights make its Ix, Iy (and all sums) vanish
+        const uint32_t wtd = active ? wt : 0u, wbd = active ? wb : 0u;
         {
-            const uint32_t *pt = ldsA + (row0 + 1) * PT_S + col + 1;
-            const uint32_t *dt = ldsB + row0 * DT_S + col;
-            uint32_t pr[8], dxp[8], dyp[8];
+            // A lane reads tile rows row0..row0+9 at pair columns col..col+2.  With pixel
+            // pairs as packed 16-bit lanes, one packed op yields the Scharr terms of window
+            // columns col and col+1 at once -- exactly the {d[x], d[x+1]} operand the
+            // bilinear dot product wants, so derivatives never leave registers.
+            const uint32_t *t = ldsA + row0 * PT_S + col;
+            uint32_t pr[8];
+            s16x2 h0[10], h1[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const uint32_t q0 = t[k * PT_S], q1 = t[k * PT_S + 1], q2 = t[k * PT_S + 2];
+                const u16x2 pl = __builtin_bit_cast(u16x2, q0), pc = __builtin_bit_cast(u16x2, q1),
+                            prt = __builtin_bit_cast(u16x2, q2);
+                h0[k] = __builtin_bit_cast(s16x2, (u16x2)(prt - pl));                       // horizontal difference
+                h1[k] = __builtin_bit_cast(s16x2, (u16x2)((pl + prt) * (unsigned short)3 + pc * (unsigned short)10));  // horizontal smoothing
+                if (k >= 1 && k <= 8) pr[k - 1] = q1;
+            }
+            uint32_t dxp[8], dyp[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                pr[k] = pt[k * PT_S];
-                uint32_t d0 = dt[k * DT_S], d1 = dt[k * DT_S + 1];
-                dxp[k] = (d0 & 0xffffu) | (d1 << 16);
-                dyp[k] = (d0 >> 16) | (d1 & 0xffff0000u);
+                const s16x2 dx = (h0[k] + h0[k + 2]) * (short)3 + h0[k + 1] * (short)10;
+                const s16x2 dy = h1[k + 2] - h1[k];
+                dxp[k] = __builtin_bit_cast(uint32_t, dx);
+                dyp[k] = __builtin_bit_cast(uint32_t, dy);
+            }
+            const bool interior = ipx >= 0 && ipx + KLT_WIN < L.w && ipy >= 0 && ipy + KLT_WIN < L.h;
+            if (!interior) {
+                // the derivative image is zero outside the image
+                const uint32_t cm = ((unsigned)(ipx + col) < (unsigned)L.w ? 0xffffu : 0u) |
+                                    ((unsigned)(ipx + col + 1) < (unsigned)L.w ? 0xffff0000u : 0u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t m = (unsigned)(ipy + row0 + k) < (unsigned)L.h ? cm : 0u;
+                    dxp[k] &= m;
+                    dyp[k] &= m;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                int ival = (int)(udot2(pr[k], wt, udot2(pr[k + 1], wb, 1u << 8)) >> 9);
-                int ixval = sdot2(dxp[k], wt, sdot2(dxp[k + 1], wb, 1 << 13)) >> 14;
-                int iyval = sdot2(dyp[k], wt, sdot2(dyp[k + 1], wb, 1 << 13)) >> 14;
-                Iv[k] = (float)ival;
-                Ixv[k] = active ? (float)ixval : 0.f;
-                Iyv[k] = active ? (float)iyval : 0.f;
-                sA11 += Ixv[k] * Ixv[k];
-                sA12 += Ixv[k] * Iyv[k];
-                sA22 += Iyv[k] * Iyv[k];
+                const int ival = (int)(udot2(pr[k], wt, udot2(pr[k + 1], wb, 1u << 8)) >> 9);
+                const int ixval = sdot2(dxp[k], wtd, sdot2(dxp[k + 1], wbd, 1 << 13)) >> 14;
+                const int iyval = sdot2(dyp[k], wtd, sdot2(dyp[k + 1], wbd, 1 << 13)) >> 14;
+                Ii[k] = ival;
+                const float fx = (float)ixval, fy = (float)iyval;
+                Ixy[k] = (v2f){fx, fy};
+                // integer products below 2^24 are exact in float, so each fused step rounds
+                // exactly like "convert the product, then add"
+                s12 = __builtin_elementwise_fma((v2f){fx, fx}, Ixy[k], s12);   // (sum Ix*Ix, sum Ix*Iy)
+                sA22 = __builtin_fmaf(fy, fy, sA22);
             }
         }
-        const float A11 = wave_sum(sA11) * FLT_SCALE;
-        const float A12 = wave_sum(sA12) * FLT_SCALE;
+        const float A11 = wave_sum(s12.x) * FLT_SCALE;
+        const float A12 = wave_sum(s12.y) * FLT_SCALE;
         const float A22 = wave_sum(sA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
@@ -293,26 +331,32 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
             wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
             wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
 
-            const uint32_t *jt = ldsA + (ry + row0) * JT_S + rx + col;
+            const uint32_t *jt = ldsA + lane_jt + (ry * JT_S + rx);
             uint32_t q[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) q[k] = jt[k * JT_S];
-            float sb1 = 0.f, sb2 = 0.f;
+            v2f sb = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                int jv = (int)(udot2(q[k], wt, udot2(q[k + 1], wb, 1u << 8)) >> 9);
-                float diff = (float)jv - Iv[k];
-                sb1 += diff * Ixv[k];
-                sb2 += diff * Iyv[k];
+                const int jv = (int)(udot2(q[k], wt, udot2(q[k + 1], wb, 1u << 8)) >> 9);
+                const float diff = (float)(jv - Ii[k]);
+                sb = __builtin_elementwise_fma((v2f){diff, diff}, Ixy[k], sb);
             }
-            const float b1 = wave_sum(sb1) * FLT_SCALE;
-            const float b2 = wave_sum(sb2) * FLT_SCALE;
+            const float b1 = wave_sum(sb.x) * FLT_SCALE;
+            const float b2 = wave_sum(sb.y) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
             outx = nx + KLT_HALF; outy = ny + KLT_HALF;
-            if ((double)dx * dx + (double)dy * dy <= A.eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // delta.ddot(delta) <= eps2 is a float64 test; the float32 value decides it
+            // unless it falls inside a narrow bracket around eps2
+            const float dd = __builtin_fmaf(dx, dx, dy * dy);
+            bool conv = dd < A.eps2_lo;
+            if (!conv && !(dd > A.eps2_hi)) conv = (double)dx * dx + (double)dy * dy <= A.eps2;
+            if (conv) break;
+            // |x| < 0.01 (float64) for a float x  <=>  |x| <= 0x3C23D70A, the float just below 0.01
+            if (j > 0 && fabsf(dx + pdx) <= 0.00999999977648258209228515625f &&
+                fabsf(dy + pdy) <= 0.00999999977648258209228515625f) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
             }
@@ -370,6 +414,9 @@ static void set_params(KltArgs &a, const vo_klt_params *p)
     e = e < 0 ? 0 : (e > 10 ? 10 : e);
     a.max_iters = it;
     a.eps2 = e * e;
+    a.eps2_lo = (float)(a.eps2 * (1.0 - 1e-5));
+    a.eps2_hi = (float)(a.eps2 * (1.0 + 1e-5));
+    if (a.eps2 == 0) { a.eps2_lo = 0.f; a.eps2_hi = 0.f; }
     a.min_eig = p->min_eig;
 }
 
