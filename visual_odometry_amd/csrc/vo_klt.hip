@@ -91,6 +91,24 @@ __device__ __forceinline__ float wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Sums of two values over the 64 lanes at the price of one reduction:
+// v_permlane32_swap puts x's upper half beside its lower half and y's likewise, so
+// after one add lanes 0-31 carry x pair sums and lanes 32-63 carry y pair sums; the
+// remaining five steps stay inside the 32-lane halves.
+__device__ __forceinline__ void wave_sum2(float x, float y, float &sx, float &sy)
+{
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    v += dpp_f<0xB1, 0xf>(v);
+    v += dpp_f<0x4E, 0xf>(v);
+    v += dpp_f<0x141, 0xf>(v);
+    v += dpp_f<0x140, 0xf>(v);
+    // row_bcast15 add in one instruction (rows 1 and 3 += lane 15 of rows 0 and 2)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0" : "+v"(v));
+    sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ int refl(int i, int n)
 {
     // BORDER_REFLECT_101 for one fold on either side; positions further out are
@@ -112,8 +130,10 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 }
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
-// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.
-// Interior tiles: one unaligned 4-byte read yields three pairs (v_perm_b32).
+// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  When the tile's
+// column range lies inside the image an item is four consecutive pixels of one
+// (reflected) row = three pairs from one unaligned 4-byte read and three
+// v_perm_b32; tiles that straddle the left/right border take a per-pair byte path.
 template <int ROWS, int PAIRS, int STRIDE>
 __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
                                             int x0, int y0, int lane)
@@ -123,11 +143,9 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
     constexpr int ROUNDS = (ITEMS + 63) / 64;
     static_assert(3 * GROUPS <= STRIDE, "tile row too narrow");
     static_assert(ITEMS <= 512, "index arithmetic below assumes a small tile");
-    // rows are reflected per item, so only the column range has to lie inside the image
-    const bool inside = (x0 >= 0) && (x0 + 3 * GROUPS + 1 <= w);
-    if (inside) {
+    const unsigned pitch32 = (unsigned)pitch;
+    if ((x0 >= 0) && (x0 + 3 * GROUPS + 1 <= w)) {
         const uint8_t *base = img + x0;
-        const int pitch32 = (int)pitch;
         uint32_t q[ROUNDS];
         int dst[ROUNDS];
         // keep the per-lane item coordinates from being hoisted out of the level
@@ -143,7 +161,7 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
             const unsigned r = __umul24((unsigned)idx, RCP) >> 16;
             const unsigned g3 = 3u * ((unsigned)idx - r * GROUPS);
             const unsigned y = (unsigned)refl(y0 + (int)r, h);
-            __builtin_memcpy(&q[k], base + (__umul24(y, (unsigned)pitch32) + g3), 4);
+            __builtin_memcpy(&q[k], base + (__umul24(y, pitch32) + g3), 4);
             dst[k] = (int)(__umul24(r, (unsigned)STRIDE) + g3);
         }
 #pragma unroll
@@ -155,16 +173,14 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
         }
     } else {
         for (int idx = lane; idx < ROWS * PAIRS; idx += 64) {
-            int r = idx / PAIRS, c = idx - r * PAIRS;
-            int y = refl(y0 + r, h);
-            int xa = refl(x0 + c, w), xb = refl(x0 + c + 1, w);
-            const uint8_t *row = img + (int64_t)y * pitch;
-            lds[r * STRIDE + c] = (uint32_t)row[xa] | ((uint32_t)row[xb] << 16);
+            const int r = idx / PAIRS, c = idx - r * PAIRS;
+            const uint8_t *row = img + __umul24((unsigned)refl(y0 + r, h), pitch32);
+            lds[r * STRIDE + c] = (uint32_t)row[refl(x0 + c, w)] | ((uint32_t)row[refl(x0 + c + 1, w)] << 16);
         }
     }
 }
 
-__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
+__global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[KLT_WAVES * LDS_WAVE_DWORDS];
 
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
         wave_sync();  // region A may still be read as the coarser level's next-image tile
         stage_pairs<PT_ROWS, 23, PT_S>(ldsA, pimg, L.ppitch, L.w, L.h, ipx - 1, ipy - 1, lane);
         wave_sync();
-        int Ii[7];
+        uint32_t Ic[7];  // 256 - 512*I: accumulator seed that folds rounding and "- I" into the dot product
         v2f Ixy[7];      // template derivatives (Ix, Iy) as float pairs for packed FMAs
         v2f s12 = {0.f, 0.f};
         float sA22 = 0.f;
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
                 const int ival = (int)(udot2(pr[k], wt, udot2(pr[k + 1], wb, 1u << 8)) >> 9);
                 const int ixval = sdot2(dxp[k], wtd, sdot2(dxp[k + 1], wbd, 1 << 13)) >> 14;
                 const int iyval = sdot2(dyp[k], wtd, sdot2(dyp[k + 1], wbd, 1 << 13)) >> 14;
-                Ii[k] = ival;
+                Ic[k] = 256u - ((uint32_t)ival << 9);
                 const float fx = (float)ixval, fy = (float)iyval;
                 Ixy[k] = (v2f){fx, fy};
                 // integer products below 2^24 are exact in float, so each fused step rounds
@@ -291,17 +307,21 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
                 sA22 = __builtin_fmaf(fy, fy, sA22);
             }
         }
-        const float A11 = wave_sum(s12.x) * FLT_SCALE;
-        const float A12 = wave_sum(s12.y) * FLT_SCALE;
+        float A11, A12;
+        wave_sum2(s12.x, s12.y, A11, A12);
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE;
         const float A22 = wave_sum(sA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
+        // hardware sqrt / reciprocal (1 ulp): the sums above already differ from a scalar
+        // evaluation in the last bits through their reduction order
+        const float minEig = (A22 + A11 - __builtin_amdgcn_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) *
+                             (1.f / (float)(2 * KLT_WIN * KLT_WIN));
         errv = minEig;
         if (minEig < A.min_eig || D < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
-        D = 1.f / D;
+        D = __builtin_amdgcn_rcpf(D);
 
         // ---- Gauss-Newton iterations on the next image ----
         nx -= KLT_HALF; ny -= KLT_HALF;
@@ -338,12 +358,13 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(KltArgs A)
             v2f sb = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                const int jv = (int)(udot2(q[k], wt, udot2(q[k + 1], wb, 1u << 8)) >> 9);
-                const float diff = (float)(jv - Ii[k]);
+                // ((S + 256) >> 9) - I == (S + 256 - 512*I) >> 9 with an arithmetic shift
+                const float diff = (float)((int)udot2(q[k], wt, udot2(q[k + 1], wb, Ic[k])) >> 9);
                 sb = __builtin_elementwise_fma((v2f){diff, diff}, Ixy[k], sb);
             }
-            const float b1 = wave_sum(sb.x) * FLT_SCALE;
-            const float b2 = wave_sum(sb.y) * FLT_SCALE;
+            float b1, b2;
+            wave_sum2(sb.x, sb.y, b1, b2);
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx; ny += dy;
