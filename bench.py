@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=64)
     ap.add_argument("--ring", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal aid: every rank uses GPU 0 (one-GPU box); never used for reported numbers")
     ap.add_argument("--distinct", type=int, default=0,
                     help="development aid: synthesise only this many distinct streams and repeat them (0 = all distinct)")
     args = ap.parse_args()
@@ -115,10 +118,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     S, R = args.streams_per_gpu, args.ring
     owned = streams.shard_streams(S * world, rank, world)      # weak scaling: S streams per GPU

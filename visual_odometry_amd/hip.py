@@ -223,9 +223,10 @@ def _k_host(K) -> np.ndarray:
 def _score(ctx, fn, pa, pb, models, thr, want_masks, K=None, pa_cols=2, ms=9):
     if _is_torch(pa):
         import torch
-        pa = pa.reshape(-1, pa_cols); pb = pb.reshape(-1, 2); models = models.reshape(-1, ms)
-        assert pa.dtype == torch.float32 and pb.dtype == torch.float32 and models.dtype == torch.float64
-        assert pa.is_contiguous() and pb.is_contiguous() and models.is_contiguous()
+        pa = pa.reshape(-1, pa_cols).contiguous(); pb = pb.reshape(-1, 2).contiguous()
+        models = models.reshape(-1, ms).contiguous()
+        if not (pa.dtype == torch.float32 and pb.dtype == torch.float32 and models.dtype == torch.float64):
+            raise ValueError(f"{fn}: points must be float32 and models float64")
         n, H = pa.shape[0], models.shape[0]
         counts = torch.empty(H, dtype=torch.int32, device=pa.device)
         masks = torch.empty((H, n), dtype=torch.uint8, device=pa.device) if want_masks else None
