@@ -102,40 +102,123 @@ __device__ __forceinline__ float key_value(uint32_t k)
 
 __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ R, int64_t npix, uint32_t *__restrict__ maxkey)
 {
+    __shared__ uint32_t wave_max[4];
     const float *src = R + (int64_t)blockIdx.y * npix;
     uint32_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256)
-        m = max(m, ordered_key(src[i]));
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (((npix & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4 *v4 = reinterpret_cast<const float4 *>(src);
+        const int64_t n4 = npix >> 2;
+        for (; i + stride < n4; i += 2 * stride) {   // two independent 16-byte loads in flight
+            const float4 a = v4[i], b = v4[i + stride];
+            m = max(m, max(max(ordered_key(a.x), ordered_key(a.y)), max(ordered_key(a.z), ordered_key(a.w))));
+            m = max(m, max(max(ordered_key(b.x), ordered_key(b.y)), max(ordered_key(b.z), ordered_key(b.w))));
+        }
+        for (; i < n4; i += stride) {
+            const float4 a = v4[i];
+            m = max(m, max(max(ordered_key(a.x), ordered_key(a.y)), max(ordered_key(a.z), ordered_key(a.w))));
+        }
+    } else {
+        for (; i < npix; i += stride) m = max(m, ordered_key(src[i]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&maxkey[blockIdx.y], m);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(&maxkey[blockIdx.y], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
 }
 
-__global__ __launch_bounds__(256) void nms_candidates_kernel(const float *__restrict__ R, int w, int h, float rel_thresh,
-                                                             int radius, const uint32_t *__restrict__ maxkey,
-                                                             unsigned long long *__restrict__ cand, int cap,
-                                                             int *__restrict__ counter)
+// before/after rule of the suppression: an earlier raster neighbour wins ties
+__device__ __forceinline__ bool beaten(float q, float v, bool before) { return before ? (q >= v) : (q > v); }
+
+// Stage 1: pixels above the threshold that are maxima of their 3x3 neighbourhood.
+// radius == 1: they are final (written as 64-bit keys); else their raster indices
+// go to a per-image list for the full-window test.
+__global__ __launch_bounds__(256) void nms3x3_kernel(const float *__restrict__ R, int w, int h, float rel_thresh,
+                                                     const uint32_t *__restrict__ maxkey, int final_stage,
+                                                     unsigned long long *__restrict__ cand, int cap,
+                                                     uint32_t *__restrict__ list, int list_cap, int *__restrict__ counter)
 {
+    __shared__ int s_n, s_base;
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= w || y >= h) return;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const float *src = R + (int64_t)b * w * h;
     const float thr = rel_thresh * key_value(maxkey[b]);
-    const float v = src[(int64_t)y * w + x];
-    if (!(v > thr)) return;
-    const int ylo = max(y - radius, 0), yhi = min(y + radius, h - 1);
-    const int xlo = max(x - radius, 0), xhi = min(x + radius, w - 1);
-    for (int yy = ylo; yy <= yhi; ++yy)
-        for (int xx = xlo; xx <= xhi; ++xx) {
-            if (xx == x && yy == y) continue;
-            const float q = src[(int64_t)yy * w + xx];
-            const bool before = (yy < y) || (yy == y && xx < x);
-            if (before ? (q >= v) : (q > v)) return;
+    float v = 0.f;
+    bool ok = x < w && y < h;
+    if (ok) {
+        v = src[(int64_t)y * w + x];
+        ok = v > thr;
+    }
+    if (ok) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0) continue;
+                const int xx = x + dx, yy = y + dy;
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+                ok = ok && !beaten(src[(int64_t)yy * w + xx], v, dy < 0 || (dy == 0 && dx < 0));
+            }
+    }
+    // block-level compaction: one global atomic per workgroup instead of one per survivor
+    const uint32_t idx = (uint32_t)(y * w + x);
+    int slot = -1;
+    if (ok) slot = atomicAdd(&s_n, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(&counter[b], s_n);
+    __syncthreads();
+    if (slot < 0) return;
+    const int pos = s_base + slot;
+    if (final_stage) {
+        if (pos < cap) cand[(int64_t)b * cap + pos] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
+    } else {
+        if (pos < list_cap) list[(int64_t)b * list_cap + pos] = idx;
+    }
+}
+
+// Stage 2: one wavefront per 3x3 maximum scans its (2r+1)^2 window, 64 neighbours
+// per step; survivors are appended as 64-bit keys.
+__global__ __launch_bounds__(256) void nms_window_kernel(const float *__restrict__ R, int w, int h, int radius,
+                                                         const uint32_t *__restrict__ list, int list_cap,
+                                                         const int *__restrict__ list_count,
+                                                         unsigned long long *__restrict__ cand, int cap,
+                                                         int *__restrict__ counter)
+{
+    __shared__ unsigned long long s_keys[4][64];   // survivors of one wave, flushed with one atomic
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = min(list_count[b], list_cap);
+    const int side = 2 * radius + 1, area = side * side;
+    const float *src = R + (int64_t)b * w * h;
+    int kept = 0;
+    for (int c = blockIdx.x * 4 + wv; c < n; c += gridDim.x * 4) {
+        const uint32_t idx = list[(int64_t)b * list_cap + c];
+        const int x = (int)(idx % (uint32_t)w), y = (int)(idx / (uint32_t)w);
+        const float v = src[idx];
+        bool lost = false;
+        for (int k = lane; k < area; k += 64) {
+            const int dy = k / side - radius, dx = k % side - radius;
+            const int xx = x + dx, yy = y + dy;
+            if ((dx | dy) != 0 && xx >= 0 && xx < w && yy >= 0 && yy < h)
+                lost = lost || beaten(src[(int64_t)yy * w + xx], v, dy < 0 || (dy == 0 && dx < 0));
         }
-    const int pos = atomicAdd(&counter[b], 1);
-    if (pos < cap) {
-        const uint32_t idx = (uint32_t)(y * w + x);
-        cand[(int64_t)b * cap + pos] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
+        if (__ballot(lost) == 0) {
+            if (lane == 0) s_keys[wv][kept] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
+            ++kept;
+        }
+        if (kept == 64 || c + gridDim.x * 4 >= n) {
+            // flush (wave-uniform): LDS accesses of one wave are ordered
+            int base = 0;
+            if (lane == 0 && kept > 0) base = atomicAdd(&counter[b], kept);
+            base = __shfl(base, 0);
+            if (lane < kept && base + lane < cap) cand[(int64_t)b * cap + base + lane] = s_keys[wv][lane];
+            kept = 0;
+        }
     }
 }
 
@@ -281,17 +364,30 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
     }
     if ((rc = vo_stage_reserve(ctx, 5, (size_t)batch * cap * 8, &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
-    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * 8, &p))) return rc;
+    // 3x3 maxima are at least 2 apart: at most ceil(h/2)*ceil(w/2) of them
+    const int list_cap = ((height + 1) / 2) * ((width + 1) / 2);
+    uint32_t *d_list = nullptr;
+    if (radius > 1) {
+        if ((rc = vo_stage_reserve(ctx, 7, (size_t)batch * list_cap * 4, &p))) return rc;
+        d_list = (uint32_t *)p;
+    }
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * 12, &p))) return rc;
     uint32_t *d_max = (uint32_t *)p;
-    int *d_counter = (int *)p + batch;
-    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * 8, ctx->stream));
-    int mblocks = (int)((npix + 256 * 8 - 1) / (256 * 8));
-    if (mblocks > 1024) mblocks = 1024;
+    int *d_counter = (int *)p + batch;       // final candidates per image
+    int *d_list_count = (int *)p + 2 * batch;  // 3x3 maxima per image
+    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * 12, ctx->stream));
+    int mblocks = (int)((npix / 4 + 256 * 4 - 1) / (256 * 4));
+    if (mblocks > 512) mblocks = 512;
+    if (mblocks < 1) mblocks = 1;
     hipLaunchKernelGGL(max_key_kernel, dim3(mblocks, batch), dim3(256), 0, ctx->stream, d_R, (int64_t)npix, d_max);
-    dim3 grid((width + 31) / 32, (height + 7) / 8, batch);
+    dim3 grid((width + 63) / 64, (height + 3) / 4, batch);
     VO_REQUIRE(grid.y <= 65535u, "vo_nms_topk: image too tall");
-    hipLaunchKernelGGL(nms_candidates_kernel, grid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh, radius,
-                       (const uint32_t *)d_max, d_cand, cap, d_counter);
+    hipLaunchKernelGGL(nms3x3_kernel, grid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh,
+                       (const uint32_t *)d_max, radius == 1 ? 1 : 0, d_cand, cap, d_list, list_cap,
+                       radius == 1 ? d_counter : d_list_count);
+    if (radius > 1)
+        hipLaunchKernelGGL(nms_window_kernel, dim3(512, batch), dim3(256), 0, ctx->stream, d_R, width, height, radius,
+                           (const uint32_t *)d_list, list_cap, (const int *)d_list_count, d_cand, cap, d_counter);
     hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), 0, ctx->stream, (const unsigned long long *)d_cand, cap,
                        (const int *)d_counter, width, K, d_xy, d_sc, d_cnt);
     VO_HIP_CHECK(hipGetLastError());
