@@ -41,17 +41,31 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
     uint8_t *dimg = dst + (int64_t)blockIdx.z * dstride;
     const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2;
 
-    // stage the input tile (consecutive threads read consecutive bytes of a row)
-    for (int idx = t; idx < PD_IH * PD_IW; idx += 256) {
-        int r = idx / PD_IW, c = idx - r * PD_IW;
-        int y = iy0 + r, x = ix0 + c;
-        // positions needed only by outputs outside the image may fall outside the
-        // reflect range; clamp them (their results are never stored)
-        y = min(max(y, -(sh - 1)), 2 * sh - 2);
-        x = min(max(x, -(sw - 1)), 2 * sw - 2);
-        y = sh > 1 ? reflect101(y, sh) : 0;
-        x = sw > 1 ? reflect101(x, sw) : 0;
-        tile[r * PD_IS + c] = simg[(int64_t)y * spitch + x];
+    // stage the input tile.  Interior tiles: unaligned 4-byte reads, consecutive lanes
+    // on consecutive dwords of a row (33 dwords cover the 131 bytes needed); tiles
+    // touching the image border read bytes with REFLECT_101 applied.
+    const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + 4 * (PD_IS / 4) <= sw && iy0 + PD_IH <= sh;
+    if (interior) {
+        const uint8_t *base = simg + (int64_t)iy0 * spitch + ix0;
+        uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
+        for (int idx = t; idx < PD_IH * (PD_IS / 4); idx += 256) {
+            int r = idx / (PD_IS / 4), c = idx - r * (PD_IS / 4);
+            uint32_t q;
+            __builtin_memcpy(&q, base + (int64_t)r * spitch + 4 * c, 4);
+            tile32[idx] = q;
+        }
+    } else {
+        for (int idx = t; idx < PD_IH * PD_IW; idx += 256) {
+            int r = idx / PD_IW, c = idx - r * PD_IW;
+            int y = iy0 + r, x = ix0 + c;
+            // positions needed only by outputs outside the image may fall outside the
+            // reflect range; clamp them (their results are never stored)
+            y = min(max(y, -(sh - 1)), 2 * sh - 2);
+            x = min(max(x, -(sw - 1)), 2 * sw - 2);
+            y = sh > 1 ? reflect101(y, sh) : 0;
+            x = sw > 1 ? reflect101(x, sw) : 0;
+            tile[r * PD_IS + c] = simg[(int64_t)y * spitch + x];
+        }
     }
     __syncthreads();
 
