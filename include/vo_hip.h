@@ -158,6 +158,25 @@ int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, i
 int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, int width, float rel_thresh, int radius,
                 int K, float *xy, float *scores, int32_t *count, int mem);
 
+/* ---- minimal solvers (model generators of the two RANSAC calls) ---------------
+ * vo_p3p_solve: per sample of four 2D-3D pairs, the P3P pose of pairs 0..2 that
+ * best reprojects pair 3 -- the candidate generator inside
+ * cv.solvePnPRansac(flags=SOLVEPNP_P3P) (vo_pipeline/poseEstimation.py:61-69).
+ * X: (n,3) float32; x: (n,2) float32; K: (3,3) float64 row-major (host pointer);
+ * subsets: (S,4) int32; Rt: (S,12) float64 [R|t] (zeros when invalid);
+ * valid: (S) uint8.
+ */
+int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, const double *K, const int32_t *subsets,
+                 int S, double *Rt, uint8_t *valid, int mem);
+/* vo_seven_point_solve: per sample of seven correspondences, the 1..3 fundamental
+ * matrices of the 7-point algorithm -- the candidate generator inside
+ * cv2.findFundamentalMat(FM_RANSAC) (vo_pipeline/bootstrap.py:246-252).
+ * m1, m2: (n,2) float32; subsets: (S,7) int32; F: (S,3,9) float64 (unused slots
+ * zero); nsol: (S) int32.
+ */
+int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m2, int n, const int32_t *subsets, int S,
+                         double *F, int32_t *nsol, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,96 @@
+"""Independent numpy minimal solvers (7-point F, Grunert P3P) -- test infrastructure:
+the checker for the GPU solvers in visual_odometry_amd/csrc/vo_solvers.hip.  Candidate
+generators of cv2.findFundamentalMat(FM_RANSAC) (reference vo_pipeline/bootstrap.py:246-252)
+and cv.solvePnPRansac(P3P) (vo_pipeline/poseEstimation.py:61-69); cv2 is absent, so these
+restate the textbook algorithms (PARITY UNPINNED against OpenCV's own solvers)."""
+from typing import Tuple
+
+import numpy as np
+
+
+def seven_point(m1: np.ndarray, m2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Batched 7-point algorithm.  m1, m2: (S,7,2).  -> (F (C,3,3) with F[2,2] = 1 where possible,
+    owner (C,) sample index of each solution); 1..3 real solutions per sample."""
+    S = m1.shape[0]
+    x1, y1, x2, y2 = m1[..., 0], m1[..., 1], m2[..., 0], m2[..., 1]
+    A = np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones_like(x1)], axis=-1).astype(np.float64)
+    _, _, Vt = np.linalg.svd(A)
+    f1, f2 = Vt[:, 7].reshape(S, 3, 3), Vt[:, 8].reshape(S, 3, 3)
+    # det(l f1 + (1-l) f2) is a cubic in l: fit it through four evaluations
+    ls = np.array([0.0, 1.0, -1.0, 2.0])
+    dets = np.stack([np.linalg.det(l * f1 + (1 - l) * f2) for l in ls], axis=-1)
+    V = np.vander(ls, 4)                       # columns l^3 l^2 l 1
+    coef = np.linalg.solve(V, dets.T).T        # (S,4): c3 c2 c1 c0
+    Fs, owner = [], []
+    for s in range(S):
+        c = coef[s]
+        if abs(c[0]) < 1e-300:
+            roots = np.roots(c[1:]) if np.any(np.abs(c[1:]) > 0) else np.array([])
+        else:
+            roots = np.roots(c)
+        for r in roots:
+            if abs(r.imag) > 1e-10 * max(1.0, abs(r.real)):
+                continue
+            F = r.real * f1[s] + (1 - r.real) * f2[s]
+            if abs(F[2, 2]) > np.finfo(np.float64).eps:
+                F = F / F[2, 2]
+            Fs.append(F)
+            owner.append(s)
+    if not Fs:
+        return np.zeros((0, 3, 3)), np.zeros(0, np.int64)
+    return np.stack(Fs), np.asarray(owner, np.int64)
+
+
+def _absolute_orientation(P: np.ndarray, Q: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """R, t with Q = R P + t for three point pairs (rows), via orthonormal triads."""
+    def triad(A):
+        e1 = A[1] - A[0]
+        e1 = e1 / np.linalg.norm(e1)
+        e3 = np.cross(e1, A[2] - A[0])
+        e3 = e3 / np.linalg.norm(e3)
+        return np.stack([e1, np.cross(e3, e1), e3], axis=1)
+    R = triad(Q) @ triad(P).T
+    return R, Q[0] - R @ P[0]
+
+
+def p3p(X3: np.ndarray, bearings: np.ndarray):
+    """Grunert's P3P for one sample.  X3: (3,3) world points, bearings: (3,3) unit rays.
+    -> list of (R, t) world->camera (up to 4)."""
+    P1, P2, P3 = X3
+    j1, j2, j3 = bearings
+    a2, b2, c2 = np.sum((P2 - P3) ** 2), np.sum((P1 - P3) ** 2), np.sum((P1 - P2) ** 2)
+    if min(a2, b2, c2) < 1e-24:
+        return []
+    ca, cb, cg = j2 @ j3, j1 @ j3, j1 @ j2
+    q = (a2 - c2) / b2
+    p = (a2 + c2) / b2
+    A4 = (q - 1) ** 2 - 4 * c2 / b2 * ca ** 2
+    A3 = 4 * (q * (1 - q) * cb - (1 - p) * ca * cg + 2 * c2 / b2 * ca ** 2 * cb)
+    A2 = 2 * (q ** 2 - 1 + 2 * q ** 2 * cb ** 2 + 2 * (b2 - c2) / b2 * ca ** 2 - 4 * p * ca * cb * cg + 2 * (b2 - a2) / b2 * cg ** 2)
+    A1 = 4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg ** 2 * cb - (1 - p) * ca * cg)
+    A0 = (1 + q) ** 2 - 4 * a2 / b2 * cg ** 2
+    coef = np.array([A4, A3, A2, A1, A0])
+    if not np.all(np.isfinite(coef)) or np.all(coef == 0):
+        return []
+    sols = []
+    for v in np.roots(coef):
+        if abs(v.imag) > 1e-8 * max(1.0, abs(v.real)) or v.real <= 0:
+            continue
+        v = v.real
+        den = 2 * (cg - v * ca)
+        if abs(den) < 1e-14:
+            continue
+        u = ((q - 1) * v * v - 2 * q * cb * v + 1 + q) / den
+        if u <= 0:
+            continue
+        d = 1 + v * v - 2 * v * cb
+        if d <= 0:
+            continue
+        s1 = np.sqrt(b2 / d)
+        Q = np.stack([s1 * j1, u * s1 * j2, v * s1 * j3])
+        R, t = _absolute_orientation(X3, Q)
+        if np.all(np.isfinite(R)) and np.all(np.isfinite(t)):
+            sols.append((R, t))
+    return sols
+
+

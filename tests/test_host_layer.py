@@ -102,10 +102,12 @@ def test_ransac_iteration_rule_and_replay():
     assert all(len(set(r)) == 7 for r in s1) and s1.min() >= 0 and s1.max() < 50
 
 
-def test_seven_point_and_p3p_on_planted_geometry():
+def test_numpy_solvers_on_planted_geometry():
+    """The independent numpy solvers (checkers of the GPU solvers) recover planted geometry."""
+    from oracle import solvers_np
     sc = synth.two_view_scene(n=60, noise=0.0, inlier_frac=1.0, seed=11)
     idx = np.arange(14).reshape(2, 7)
-    Fs, owner = ransac.seven_point(sc["m1"][idx].astype(np.float64), sc["m2"][idx].astype(np.float64))
+    Fs, owner = solvers_np.seven_point(sc["m1"][idx].astype(np.float64), sc["m2"][idx].astype(np.float64))
     assert Fs.shape[0] >= 2 and set(owner) == {0, 1}
     m1h = np.hstack([sc["m1"], np.ones((60, 1))]).astype(np.float64)
     m2h = np.hstack([sc["m2"], np.ones((60, 1))]).astype(np.float64)
@@ -115,7 +117,7 @@ def test_seven_point_and_p3p_on_planted_geometry():
     rays = (Kinv @ m2h.T).T
     rays /= np.linalg.norm(rays, axis=1, keepdims=True)
     X = sc["X"].astype(np.float64)
-    sols = ransac.p3p(X[:3], rays[:3])
+    sols = solvers_np.p3p(X[:3], rays[:3])
     assert sols
     err = min(np.abs(R - sc["R"]).max() + np.abs(t - sc["t"]).max() for R, t in sols)
     assert err < 1e-3

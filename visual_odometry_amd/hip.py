@@ -363,3 +363,50 @@ def nms_topk(ctx: Context, R, K: int, rel_thresh: float = 0.01, radius: int = 1)
     check(ctx.lib.vo_nms_topk(ctx.handle, _ptr(t), B, H, W, float(rel_thresh), int(radius), int(K), _ptr(xy), _ptr(sc),
                               _ptr(cnt), mem), "vo_nms_topk")
     return xy, sc, cnt
+
+
+def p3p_solve(ctx: Context, X, x, K, subsets):
+    """P3P per 4-point sample -> (Rt (S,3,4) f64, valid (S,) u8).  subsets: (S,4) int32."""
+    Kh = _k_host(K)
+    if _is_torch(X):
+        import torch
+        X = X.reshape(-1, 3).contiguous(); x = x.reshape(-1, 2).contiguous()
+        subsets = subsets.reshape(-1, 4).to(torch.int32).contiguous()
+        S = subsets.shape[0]
+        Rt = torch.empty((S, 3, 4), dtype=torch.float64, device=X.device)
+        valid = torch.empty(S, dtype=torch.uint8, device=X.device)
+        mem = VO_MEM_DEVICE
+    else:
+        X = np.ascontiguousarray(X, np.float32).reshape(-1, 3); x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
+        subsets = np.ascontiguousarray(subsets, np.int32).reshape(-1, 4)
+        S = subsets.shape[0]
+        Rt = np.zeros((S, 3, 4)); valid = np.zeros(S, np.uint8)
+        mem = VO_MEM_HOST
+    if x.shape[0] != X.shape[0]:
+        raise ValueError("p3p_solve: point sets differ in length")
+    check(ctx.lib.vo_p3p_solve(ctx.handle, _ptr(X), _ptr(x), int(X.shape[0]), Kh.ctypes.data_as(_lib.c_f64p), _ptr(subsets),
+                               int(S), _ptr(Rt), _ptr(valid), mem), "vo_p3p_solve")
+    return Rt, valid
+
+
+def seven_point_solve(ctx: Context, m1, m2, subsets):
+    """7-point algorithm per sample -> (F (S,3,3,3) f64 -- up to three matrices each, nsol (S,) i32)."""
+    if _is_torch(m1):
+        import torch
+        m1 = m1.reshape(-1, 2).contiguous(); m2 = m2.reshape(-1, 2).contiguous()
+        subsets = subsets.reshape(-1, 7).to(torch.int32).contiguous()
+        S = subsets.shape[0]
+        F = torch.empty((S, 3, 3, 3), dtype=torch.float64, device=m1.device)
+        ns = torch.empty(S, dtype=torch.int32, device=m1.device)
+        mem = VO_MEM_DEVICE
+    else:
+        m1 = np.ascontiguousarray(m1, np.float32).reshape(-1, 2); m2 = np.ascontiguousarray(m2, np.float32).reshape(-1, 2)
+        subsets = np.ascontiguousarray(subsets, np.int32).reshape(-1, 7)
+        S = subsets.shape[0]
+        F = np.zeros((S, 3, 3, 3)); ns = np.zeros(S, np.int32)
+        mem = VO_MEM_HOST
+    if m2.shape[0] != m1.shape[0]:
+        raise ValueError("seven_point_solve: point sets differ in length")
+    check(ctx.lib.vo_seven_point_solve(ctx.handle, _ptr(m1), _ptr(m2), int(m1.shape[0]), _ptr(subsets), int(S), _ptr(F),
+                                       _ptr(ns), mem), "vo_seven_point_solve")
+    return F, ns

@@ -5,12 +5,13 @@ Stand-ins for the two cv2 calls of the hot path:
   cv.solvePnPRansac(X, x, K, None, flags=SOLVEPNP_P3P, ...)                vo_pipeline/poseEstimation.py:61-69
 
 Structure: the host draws every minimal sample up front with OpenCV's generator
-and subset rule, solves all minimal problems in batched numpy (7-point F, P3P),
-the GPU scores every candidate against every correspondence in one launch
-(vo_score_fundamental / vo_score_pnp), and the host replays OpenCV's sequential
-loop over the counts -- best-so-far update, adaptive iteration count, early stop
--- so the outcome equals that loop run on the same candidate sequence.  The
-minimal solvers are independent implementations (same geometry, different
+and subset rule,
+the GPU solves all minimal problems (vo_seven_point_solve / vo_p3p_solve, one
+sample per lane) and scores every candidate against every correspondence in one
+launch (vo_score_fundamental / vo_score_pnp), and the host replays OpenCV's
+sequential loop over the counts -- best-so-far update, adaptive iteration count,
+early stop -- so the outcome equals that loop run on the same candidate sequence.
+The minimal solvers are independent implementations (same geometry, different
 numerics than OpenCV's), so candidates agree with cv2 only to solver precision.
 """
 from typing import Optional, Tuple
@@ -98,40 +99,7 @@ def replay_ransac_loop(counts: np.ndarray, owner: np.ndarray, n: int, model_poin
     return best_c
 
 
-# ---------------------------------------------------------------- 7-point F
-def seven_point(m1: np.ndarray, m2: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Batched 7-point algorithm.  m1, m2: (S,7,2).  -> (F (C,3,3) with F[2,2] = 1 where possible,
-    owner (C,) sample index of each solution); 1..3 real solutions per sample."""
-    S = m1.shape[0]
-    x1, y1, x2, y2 = m1[..., 0], m1[..., 1], m2[..., 0], m2[..., 1]
-    A = np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones_like(x1)], axis=-1).astype(np.float64)
-    _, _, Vt = np.linalg.svd(A)
-    f1, f2 = Vt[:, 7].reshape(S, 3, 3), Vt[:, 8].reshape(S, 3, 3)
-    # det(l f1 + (1-l) f2) is a cubic in l: fit it through four evaluations
-    ls = np.array([0.0, 1.0, -1.0, 2.0])
-    dets = np.stack([np.linalg.det(l * f1 + (1 - l) * f2) for l in ls], axis=-1)
-    V = np.vander(ls, 4)                       # columns l^3 l^2 l 1
-    coef = np.linalg.solve(V, dets.T).T        # (S,4): c3 c2 c1 c0
-    Fs, owner = [], []
-    for s in range(S):
-        c = coef[s]
-        if abs(c[0]) < 1e-300:
-            roots = np.roots(c[1:]) if np.any(np.abs(c[1:]) > 0) else np.array([])
-        else:
-            roots = np.roots(c)
-        for r in roots:
-            if abs(r.imag) > 1e-10 * max(1.0, abs(r.real)):
-                continue
-            F = r.real * f1[s] + (1 - r.real) * f2[s]
-            if abs(F[2, 2]) > np.finfo(np.float64).eps:
-                F = F / F[2, 2]
-            Fs.append(F)
-            owner.append(s)
-    if not Fs:
-        return np.zeros((0, 3, 3)), np.zeros(0, np.int64)
-    return np.stack(Fs), np.asarray(owner, np.int64)
-
-
+# ---------------------------------------------------------------- F by RANSAC
 def find_fundamental_mat(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: float, max_iters: int,
                          device: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
     """-> (F (3,3) float64 or None, mask (n,1) uint8), as cv2.findFundamentalMat(..., FM_RANSAC, ...)."""
@@ -144,10 +112,13 @@ def find_fundamental_mat(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: f
         return None, np.zeros((n, 1), np.uint8)
     rng = CvRNG()
     subsets = draw_subsets(rng, n, 7, int(max_iters), m1, m2)
-    Fs, owner = seven_point(m1[subsets], m2[subsets])
+    ctx = _runtime.context(device)
+    Fall, nsol = hip.seven_point_solve(ctx, m1, m2, subsets)          # (S,3,3,3), (S,)
+    slot = np.arange(3)[None, :] < nsol[:, None]                      # real solutions per sample
+    owner = np.repeat(np.arange(subsets.shape[0]), 3)[slot.ravel()]
+    Fs = Fall.reshape(-1, 3, 3)[slot.ravel()]
     if Fs.shape[0] == 0:
         return None, np.zeros((n, 1), np.uint8)
-    ctx = _runtime.context(device)
     counts, _ = hip.score_fundamental(ctx, m1, m2, Fs, thr, want_masks=False)
     win = replay_ransac_loop(counts, owner, n, 7, conf, int(max_iters))
     if win < 0:
@@ -156,60 +127,7 @@ def find_fundamental_mat(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: f
     return Fs[win].copy(), mask.reshape(n, 1)
 
 
-# ---------------------------------------------------------------- P3P
-def _absolute_orientation(P: np.ndarray, Q: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """R, t with Q = R P + t for three point pairs (rows), via orthonormal triads."""
-    def triad(A):
-        e1 = A[1] - A[0]
-        e1 = e1 / np.linalg.norm(e1)
-        e3 = np.cross(e1, A[2] - A[0])
-        e3 = e3 / np.linalg.norm(e3)
-        return np.stack([e1, np.cross(e3, e1), e3], axis=1)
-    R = triad(Q) @ triad(P).T
-    return R, Q[0] - R @ P[0]
-
-
-def p3p(X3: np.ndarray, bearings: np.ndarray):
-    """Grunert's P3P for one sample.  X3: (3,3) world points, bearings: (3,3) unit rays.
-    -> list of (R, t) world->camera (up to 4)."""
-    P1, P2, P3 = X3
-    j1, j2, j3 = bearings
-    a2, b2, c2 = np.sum((P2 - P3) ** 2), np.sum((P1 - P3) ** 2), np.sum((P1 - P2) ** 2)
-    if min(a2, b2, c2) < 1e-24:
-        return []
-    ca, cb, cg = j2 @ j3, j1 @ j3, j1 @ j2
-    q = (a2 - c2) / b2
-    p = (a2 + c2) / b2
-    A4 = (q - 1) ** 2 - 4 * c2 / b2 * ca ** 2
-    A3 = 4 * (q * (1 - q) * cb - (1 - p) * ca * cg + 2 * c2 / b2 * ca ** 2 * cb)
-    A2 = 2 * (q ** 2 - 1 + 2 * q ** 2 * cb ** 2 + 2 * (b2 - c2) / b2 * ca ** 2 - 4 * p * ca * cb * cg + 2 * (b2 - a2) / b2 * cg ** 2)
-    A1 = 4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg ** 2 * cb - (1 - p) * ca * cg)
-    A0 = (1 + q) ** 2 - 4 * a2 / b2 * cg ** 2
-    coef = np.array([A4, A3, A2, A1, A0])
-    if not np.all(np.isfinite(coef)) or np.all(coef == 0):
-        return []
-    sols = []
-    for v in np.roots(coef):
-        if abs(v.imag) > 1e-8 * max(1.0, abs(v.real)) or v.real <= 0:
-            continue
-        v = v.real
-        den = 2 * (cg - v * ca)
-        if abs(den) < 1e-14:
-            continue
-        u = ((q - 1) * v * v - 2 * q * cb * v + 1 + q) / den
-        if u <= 0:
-            continue
-        d = 1 + v * v - 2 * v * cb
-        if d <= 0:
-            continue
-        s1 = np.sqrt(b2 / d)
-        Q = np.stack([s1 * j1, u * s1 * j2, v * s1 * j3])
-        R, t = _absolute_orientation(X3, Q)
-        if np.all(np.isfinite(R)) and np.all(np.isfinite(t)):
-            sols.append((R, t))
-    return sols
-
-
+# ---------------------------------------------------------------- PnP by RANSAC
 def refine_pose(ctx, X: np.ndarray, x: np.ndarray, K: np.ndarray, R: np.ndarray, t: np.ndarray, iters: int = 10):
     """Gauss-Newton on the reprojection error over the given correspondences (pose only); the
     6x6 normal equations come from the GPU BA kernel with the points held fixed."""
@@ -252,29 +170,12 @@ def solve_pnp_ransac(X: np.ndarray, x: np.ndarray, K: np.ndarray, thr: float, co
     Kd = np.asarray(K, np.float64).reshape(3, 3)
     rng = CvRNG()
     subsets = draw_subsets(rng, n, 4, int(max_iters))
-    Kinv = np.linalg.inv(Kd)
-    rays = (Kinv @ np.hstack([x.astype(np.float64), np.ones((n, 1))]).T).T
-    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
-    Xd = X.astype(np.float64)
-    cands, owner = [], []
-    for s, idx in enumerate(subsets):
-        best, best_e = None, np.inf
-        for R, t in p3p(Xd[idx[:3]], rays[idx[:3]]):
-            pc = R @ Xd[idx[3]] + t
-            if pc[2] <= 0:
-                continue
-            uv = Kd @ pc
-            e = np.sum((uv[:2] / uv[2] - x[idx[3]]) ** 2)
-            if e < best_e:
-                best, best_e = (R, t), e
-        if best is not None:
-            cands.append(np.hstack([best[0], best[1][:, None]]))
-            owner.append(s)
-    if not cands:
-        return False, np.eye(3), np.zeros(3), empty
-    Rt = np.stack(cands)
-    owner = np.asarray(owner, np.int64)
     ctx = _runtime.context(device)
+    Rt_all, valid = hip.p3p_solve(ctx, X, x, Kd, subsets)              # one candidate per sample
+    owner = np.nonzero(valid)[0].astype(np.int64)
+    if owner.size == 0:
+        return False, np.eye(3), np.zeros(3), empty
+    Rt = Rt_all[owner]
     counts, _ = hip.score_pnp(ctx, X, x, Kd, Rt, thr, want_masks=False)
     win = replay_ransac_loop(counts, owner, n, 4, conf, int(max_iters))
     if win < 0:
