@@ -321,9 +321,13 @@ extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, in
         void *p;
         if ((rc = vo_stage_reserve(ctx, 0, npix * batch, &p))) return rc; d_img = (const uint8_t *)p;
         if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc; d_R = (float *)p;
-        for (int b = 0; b < batch; ++b)
-            VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride, width,
-                                          height, hipMemcpyHostToDevice, ctx->stream));
+        if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
+            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            for (int b = 0; b < batch; ++b)
+                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
+                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+        }
         pitch = width; istride = (int64_t)npix;
     }
     dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);

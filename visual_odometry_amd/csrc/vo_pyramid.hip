@@ -183,10 +183,15 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
             if (e != hipSuccess) { vo_set_error("vo_pyr_build: device allocation of %zu bytes failed", need); return VO_ENOMEM; }
             pyr->own0_bytes = need;
         }
-        for (int b = 0; b < pyr->batch; ++b)
-            VO_HIP_CHECK(hipMemcpy2DAsync(pyr->own0 + (size_t)b * pyr->w[0] * pyr->h[0], pyr->w[0],
-                                          img + (size_t)b * img_stride, row_stride, pyr->w[0], pyr->h[0],
-                                          hipMemcpyHostToDevice, ctx->stream));
+        const size_t img_bytes = (size_t)pyr->w[0] * pyr->h[0];
+        if (row_stride == pyr->w[0] && (pyr->batch == 1 || img_stride == (int64_t)img_bytes)) {
+            // tight input: one linear copy (2-D copies from pageable memory go row by row)
+            VO_HIP_CHECK(hipMemcpyAsync(pyr->own0, img, img_bytes * pyr->batch, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            for (int b = 0; b < pyr->batch; ++b)
+                VO_HIP_CHECK(hipMemcpy2DAsync(pyr->own0 + b * img_bytes, pyr->w[0], img + (size_t)b * img_stride, row_stride,
+                                              pyr->w[0], pyr->h[0], hipMemcpyHostToDevice, ctx->stream));
+        }
         pyr->lvl[0] = pyr->own0;
         pyr->pitch[0] = pyr->w[0];
         pyr->img_stride[0] = (int64_t)pyr->w[0] * pyr->h[0];
