@@ -118,6 +118,22 @@ __device__ __forceinline__ int refl(int i, int n)
     return min(max(i, 0), n - 1);
 }
 
+// Packed 14-bit bilinear weights {iw00, iw01} and {iw10, iw11} for the fractional
+// offsets (a, b): iw = cvRound(w * 2^14), iw11 = 2^14 - iw00 - iw01 - iw10.  Adding
+// 1.5 * 2^23 rounds to nearest-even and leaves the integer in the low mantissa bits,
+// so everything stays on full-rate add/and/shift instructions (v_cvt_i32_f32 is half rate).
+__device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wt, uint32_t &wb)
+{
+    const float magic = 12582912.0f;               // 0x4B400000
+    const float ia = 1.f - a, ib = 1.f - b;
+    const uint32_t t00 = __float_as_uint(ia * ib * 16384.f + magic);
+    const uint32_t t01 = __float_as_uint(a * ib * 16384.f + magic);
+    const uint32_t t10 = __float_as_uint(ia * b * 16384.f + magic);
+    const uint32_t iw11 = (16384u + 3u * 0x4B400000u) - (t00 + t01 + t10);
+    wt = (t00 & 0xffffu) | (t01 << 16);
+    wb = (t10 & 0xffffu) | (iw11 << 16);
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
@@ -233,18 +249,14 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
         outx = nx; outy = ny;
 
         px -= KLT_HALF; py -= KLT_HALF;
-        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
+        const float fpx = floorf(px), fpy = floorf(py);
+        const int ipx = uniform((int)fpx), ipy = uniform((int)fpy);
         if (ipx < -KLT_WIN || ipx >= L.w || ipy < -KLT_WIN || ipy >= L.h) {
             if (level == 0) { status = 0; errv = 0.f; }
             continue;
         }
-        float a = px - (float)ipx, b = py - (float)ipy;
-        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-        int iw01 = __float2int_rn(a * (1.f - b) * 16384.f);
-        int iw10 = __float2int_rn((1.f - a) * b * 16384.f);
-        int iw11 = 16384 - iw00 - iw01 - iw10;
-        uint32_t wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
-        uint32_t wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
+        uint32_t wt, wb;
+        bilinear_weights(px - fpx, py - fpy, wt, wb);
 
         // ---- template: previous-image tile -> Scharr pairs in registers -> bilinear samples ----
         wave_sync();  // region A may still be read as the coarser level's next-image tile
@@ -329,7 +341,8 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
         int ox = 0, oy = 0;
         bool have_tile = false;
         for (int j = 0; j < A.max_iters; ++j) {
-            const int inx = uniform((int)floorf(nx)), iny = uniform((int)floorf(ny));
+            const float fnx = floorf(nx), fny = floorf(ny);
+            const int inx = uniform((int)fnx), iny = uniform((int)fny);
             if (inx < -KLT_WIN || inx >= L.w || iny < -KLT_WIN || iny >= L.h) {
                 if (level == 0) status = 0;
                 break;
@@ -343,13 +356,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
                 wave_sync();
                 have_tile = true;
             }
-            a = nx - (float)inx; b = ny - (float)iny;
-            iw00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-            iw01 = __float2int_rn(a * (1.f - b) * 16384.f);
-            iw10 = __float2int_rn((1.f - a) * b * 16384.f);
-            iw11 = 16384 - iw00 - iw01 - iw10;
-            wt = (uint32_t)iw00 | ((uint32_t)iw01 << 16);
-            wb = (uint32_t)iw10 | ((uint32_t)iw11 << 16);
+            bilinear_weights(nx - fnx, ny - fny, wt, wb);
 
             const uint32_t *jt = ldsA + lane_jt + (ry * JT_S + rx);
             uint32_t q[8];
