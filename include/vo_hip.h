@@ -177,6 +177,17 @@ int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, const doubl
 int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m2, int n, const int32_t *subsets, int S,
                          double *F, int32_t *nsol, int mem);
 
+/* ---- two-view geometry ---------------------------------------------------------
+ * vo_triangulate replaces BootstrapInitializer._linear_triangulation
+ * (vo_pipeline/bootstrap.py:141-156): per pair the null vector of
+ * [ [p1]x M1 ; [p2]x M2 ], stored as float32 and divided by its last component.
+ * pts1, pts2: (n,3) float32 homogeneous pixels; M1, M2: (3,4) float64 row-major,
+ * host pointers; m*_is_f32 != 0 forms [p]x M in float32 (the reference's M1 is
+ * float32); out: (n,4) float32.
+ */
+int vo_triangulate(vo_ctx *ctx, const float *pts1, const float *pts2, int n, const double *M1, const double *M2,
+                   int m1_is_f32, int m2_is_f32, float *out, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,3 +94,23 @@ def p3p(X3: np.ndarray, bearings: np.ndarray):
     return sols
 
 
+
+
+def linear_triangulation(pts1, pts2, M1, M2):
+    """DLT triangulation as BootstrapInitializer._linear_triangulation does it
+    (vo_pipeline/bootstrap.py:141-156): per pair, A = [[p1]x M1; [p2]x M2], P = last right
+    singular vector stored as float32, divided by its last component.  Pinned by
+    tests/golden/two_view.npz (output of the reference function)."""
+    pts1 = np.asarray(pts1)
+    pts2 = np.asarray(pts2)
+    n = pts1.shape[0]
+    P = np.zeros((n, 4), dtype=np.float32)
+
+    def cross_matrix(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.float32)
+
+    for i in range(n):
+        A = np.vstack((cross_matrix(pts1[i]) @ M1, cross_matrix(pts2[i]) @ M2))
+        _, _, VT = np.linalg.svd(A, full_matrices=False)
+        P[i] = VT[-1]
+    return (P.T / P[:, 3]).T

@@ -157,3 +157,34 @@ def test_pose_graph_optimizer_motion_only(ctx):
     assert opt.optimize() == 1
     np.testing.assert_allclose(fs.pose[:3, :3], sc["R"], atol=1e-3)
     np.testing.assert_allclose(fs.pose[:3, 3], sc["t"], atol=2e-2)
+
+
+def test_two_view_geometry_matches_reference(ctx):
+    """GPU triangulation and the cheirality selection built on it against the reference's own
+    outputs (tests/golden/two_view.npz, written by tools/gen_golden.py from the reference functions)."""
+    from visual_odometry_amd import hip
+    from visual_odometry_amd.vo_pipeline import bootstrap
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "two_view.npz"))
+    tri = bootstrap.BootstrapInitializer._linear_triangulation(d["p1"], d["p2"], d["M1"], d["M2"])
+    assert tri.dtype == np.float32 and tri.shape == d["tri"].shape
+    np.testing.assert_allclose(tri, d["tri"], rtol=1e-5, atol=1e-5)
+    b = object.__new__(bootstrap.BootstrapInitializer)
+    b.K, b.max_point_dist = d["K"], float(d["max_point_dist"])
+    T, cloud, mask = b._transform_matrix(d["F"], d["p1"], d["p2"])
+    np.testing.assert_allclose(T, d["T"], atol=1e-6)
+    np.testing.assert_allclose(cloud, d["cloud"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_array_equal(mask, d["mask"])
+    np.testing.assert_allclose(T[:3, :3], d["R_true"], atol=1e-3)
+    np.testing.assert_allclose(T[:3, 3], d["t_true"], atol=1e-3)
+    # device-resident inputs, float64 projection matrices, empty input
+    import torch
+    t1, t2 = torch.from_numpy(d["p1"]).cuda(), torch.from_numpy(d["p2"]).cuda()
+    tri_d = hip.triangulate(ctx, t1, t2, d["M1"], d["M2"]).cpu().numpy()
+    np.testing.assert_array_equal(tri_d, tri)
+    from oracle import solvers_np
+    M1d = d["M1"].astype(np.float64)
+    ref = solvers_np.linear_triangulation(d["p1"], d["p2"], M1d, d["M2"])
+    np.testing.assert_allclose(hip.triangulate(ctx, d["p1"], d["p2"], M1d, d["M2"]), ref, rtol=1e-5, atol=1e-5)
+    assert hip.triangulate(ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), d["M1"], d["M2"]).shape == (0, 4)
+    with pytest.raises(ValueError):
+        hip.triangulate(ctx, d["p1"], d["p2"][:-1], d["M1"], d["M2"])

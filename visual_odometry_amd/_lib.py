@@ -58,6 +58,8 @@ SIGNATURES = {
                                     ctypes.c_int]),
     "vo_seven_point_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp,
                                             ctypes.c_int]),
+    "vo_triangulate": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int, c_vp,
+                                      ctypes.c_int]),
 }
 
 _lib = None

@@ -410,3 +410,27 @@ def seven_point_solve(ctx: Context, m1, m2, subsets):
     check(ctx.lib.vo_seven_point_solve(ctx.handle, _ptr(m1), _ptr(m2), int(m1.shape[0]), _ptr(subsets), int(S), _ptr(F),
                                        _ptr(ns), mem), "vo_seven_point_solve")
     return F, ns
+
+
+def triangulate(ctx: Context, pts1, pts2, M1, M2):
+    """DLT triangulation of homogeneous pixel pairs (n,3) float32 -> (n,4) float32 (last column 1).
+    [p]x M is formed in float32 for a float32 projection matrix, like the reference's numpy product."""
+    f1 = getattr(M1, "dtype", None) == np.float32
+    f2 = getattr(M2, "dtype", None) == np.float32
+    A = np.ascontiguousarray(M1, np.float64).reshape(3, 4)
+    B = np.ascontiguousarray(M2, np.float64).reshape(3, 4)
+    if _is_torch(pts1):
+        import torch
+        pts1 = pts1.reshape(-1, 3).contiguous(); pts2 = pts2.reshape(-1, 3).contiguous()
+        out = torch.empty((pts1.shape[0], 4), dtype=torch.float32, device=pts1.device)
+        mem = VO_MEM_DEVICE
+    else:
+        pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 3)
+        pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 3)
+        out = np.zeros((pts1.shape[0], 4), np.float32)
+        mem = VO_MEM_HOST
+    if pts2.shape[0] != pts1.shape[0]:
+        raise ValueError("triangulate: point sets differ in length")
+    check(ctx.lib.vo_triangulate(ctx.handle, _ptr(pts1), _ptr(pts2), int(pts1.shape[0]), A.ctypes.data_as(_lib.c_f64p),
+                                 B.ctypes.data_as(_lib.c_f64p), int(f1), int(f2), _ptr(out), mem), "vo_triangulate")
+    return out

@@ -13,9 +13,8 @@ from typing import Tuple
 
 import numpy as np
 
-from .. import params
-from ..utils.matrix import skew
-from . import ransac
+from .. import hip, params
+from . import _runtime, ransac
 from .featureExtraction import FeatureExtractor
 from .poseEstimation import PoseEstimation
 
@@ -102,19 +101,8 @@ class BootstrapInitializer:
 
     @staticmethod
     def _linear_triangulation(pts1: np.ndarray, pts2: np.ndarray, M1: np.ndarray, M2: np.ndarray) -> np.ndarray:
-        """DLT triangulation of homogeneous pixel pairs (n,3) -> (n,4) points with last column 1
-        (float32 storage of the null vector, like the reference); batched SVD instead of a loop."""
+        """DLT triangulation of homogeneous pixel pairs (n,3) -> (n,4) float32 points with last
+        column 1; one point per GPU lane instead of the reference's per-point SVD loop."""
         assert pts1.shape == pts2.shape, "The number of matched points in both images has to be the same"
         assert M1.shape == M2.shape == (3, 4), "Homogeneous projection matrices have be of shape (3,4)"
-
-        def cross_rows(p, M):
-            # [p]x M with the float32 cross-product matrix of the reference helper
-            Sx = np.zeros((p.shape[0], 3, 3), dtype=np.float32)
-            Sx[:, 0, 1], Sx[:, 0, 2] = -p[:, 2], p[:, 1]
-            Sx[:, 1, 0], Sx[:, 1, 2] = p[:, 2], -p[:, 0]
-            Sx[:, 2, 0], Sx[:, 2, 1] = -p[:, 1], p[:, 0]
-            return Sx @ M
-        A = np.concatenate([cross_rows(pts1, M1), cross_rows(pts2, M2)], axis=1)
-        _, _, VT = np.linalg.svd(A, full_matrices=False)
-        P = VT[:, -1, :].astype(np.float32)
-        return (P.T / P[:, 3]).T
+        return hip.triangulate(_runtime.context(), pts1, pts2, M1, M2)
