@@ -147,45 +147,40 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
 // (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  When the tile's
-// column range lies inside the image an item is four consecutive pixels of one
-// (reflected) row = three pairs from one unaligned 4-byte read and three
-// v_perm_b32; tiles that straddle the left/right border take a per-pair byte path.
+// column range lies inside the image an item is half a (reflected) row: one
+// unaligned 16-byte read yields 15 pairs through v_perm_b32, and the second half
+// starts G1 pixels in so that the two reads end exactly at the last pixel the tile
+// needs (the pairs both halves produce are written twice with the same value).
+// One item per lane covers the whole tile.  Tiles that straddle the left/right
+// border take a per-pair byte path.
 template <int ROWS, int PAIRS, int STRIDE>
 __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
                                             int x0, int y0, int lane)
 {
-    constexpr int GROUPS = (PAIRS + 2) / 3;
-    constexpr int ITEMS = ROWS * GROUPS;
-    constexpr int ROUNDS = (ITEMS + 63) / 64;
-    static_assert(3 * GROUPS <= STRIDE, "tile row too narrow");
-    static_assert(ITEMS <= 512, "index arithmetic below assumes a small tile");
+    constexpr int G1 = PAIRS + 1 - 16;  // first pixel of the second half
+    static_assert(G1 >= 1 && G1 <= 15, "two 16-byte reads must cover the row");
+    static_assert(2 * ROWS <= 64, "one item per lane");
+    static_assert(PAIRS <= STRIDE, "tile row too narrow");
     const unsigned pitch32 = (unsigned)pitch;
-    if ((x0 >= 0) && (x0 + 3 * GROUPS + 1 <= w)) {
-        const uint8_t *base = img + x0;
-        uint32_t q[ROUNDS];
-        int dst[ROUNDS];
+    if ((x0 >= 0) && (x0 + PAIRS + 1 <= w)) {
         // keep the per-lane item coordinates from being hoisted out of the level
-        // loop (they would stay live in ~16 registers for the whole kernel)
+        // loop (they would stay live for the whole kernel)
         int l = lane;
         asm volatile("" : "+v"(l));
+        const int idx = min(l, 2 * ROWS - 1);  // surplus lanes repeat the last item
+        const unsigned r = (unsigned)idx >> 1;
+        const unsigned g = (idx & 1) ? (unsigned)G1 : 0u;
+        const unsigned y = (unsigned)refl(y0 + (int)r, h);
+        uint32_t q[4];
+        __builtin_memcpy(q, img + x0 + (__umul24(y, pitch32) + g), 16);
+        uint32_t *d = lds + (__umul24(r, (unsigned)STRIDE) + g);
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            int idx = l + 64 * k;
-            if (ITEMS % 64 != 0 && k == ROUNDS - 1) idx = min(idx, ITEMS - 1);  // tail lanes repeat the last item
-            // idx < 512: exact division by a small constant with one 24-bit multiply
-            constexpr unsigned RCP = (1u << 16) / GROUPS + 1;
-            const unsigned r = __umul24((unsigned)idx, RCP) >> 16;
-            const unsigned g3 = 3u * ((unsigned)idx - r * GROUPS);
-            const unsigned y = (unsigned)refl(y0 + (int)r, h);
-            __builtin_memcpy(&q[k], base + (__umul24(y, pitch32) + g3), 4);
-            dst[k] = (int)(__umul24(r, (unsigned)STRIDE) + g3);
-        }
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            uint32_t *d = lds + dst[k];
-            d[0] = __builtin_amdgcn_perm(0u, q[k], 0x0c010c00u);
-            d[1] = __builtin_amdgcn_perm(0u, q[k], 0x0c020c01u);
-            d[2] = __builtin_amdgcn_perm(0u, q[k], 0x0c030c02u);
+        for (int j = 0; j < 15; ++j) {
+            const int c = j >> 2, o = j & 3;
+            d[j] = o == 0   ? __builtin_amdgcn_perm(0u, q[c], 0x0c010c00u)
+                   : o == 1 ? __builtin_amdgcn_perm(0u, q[c], 0x0c020c01u)
+                   : o == 2 ? __builtin_amdgcn_perm(0u, q[c], 0x0c030c02u)
+                            : __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c040c03u);
         }
     } else {
         for (int idx = lane; idx < ROWS * PAIRS; idx += 64) {
