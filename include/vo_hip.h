@@ -188,6 +188,30 @@ int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m2, int n, c
 int vo_triangulate(vo_ctx *ctx, const float *pts1, const float *pts2, int n, const double *M1, const double *M2,
                    int m1_is_f32, int m2_is_f32, float *out, int mem);
 
+/* ---- bundle-adjustment solve ------------------------------------------------------
+ * Device-resident Levenberg-Marquardt state for one window; replaces the
+ * least_squares(..., method='trf') call of BundleAdjustment.bundle_adjustment
+ * (vo_pipeline/bundleAdjustment.py:96-97) on the problem defined there: parameters
+ * [F x (rvec, t) | P x XYZ], observations before obs_start without Jacobian rows
+ * (bundleAdjustment.py:54-65), cost 0.5*|r|^2.
+ *   vo_ba_create     uploads indices/observations once (ci, pi, obs follow `mem`; K is a host pointer)
+ *   vo_ba_linearize  sets the current parameters and builds residual + normal equations; cost -> host
+ *   vo_ba_try_step   candidate = current + LM step for damping lambda (Schur complement on the
+ *                    landmarks, Cholesky of the 6F x 6F camera system, back-substitution), linearised
+ *                    as well; cost_new -> host, *solved = 0 when the reduced system was not positive definite
+ *   vo_ba_accept     the candidate becomes the current point (buffer swap, nothing recomputed)
+ *   vo_ba_params     copies the current (candidate = 0) or candidate (1) parameter vector out
+ * vo_ba_linearize and vo_ba_try_step synchronise the stream (they return costs to the host).
+ */
+typedef struct vo_ba vo_ba;
+int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const double *obs,
+                 const double *K, int obs_start, int mem, vo_ba **out);
+void vo_ba_destroy(vo_ba *ba);
+int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost);
+int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved);
+int vo_ba_accept(vo_ctx *ctx, vo_ba *ba);
+int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,124 @@
+"""GPU tests of the device-resident bundle-adjustment solver (vo_ba_create / vo_ba_linearize /
+vo_ba_try_step / vo_ba_accept / vo_ba_params) against a dense numpy restatement of the same
+damped Schur step built on the CPU oracle's normal equations."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def numpy_lm_step(ne, x, F, P, ci, pi, lam):
+    """One damped step from the block normal equations: D = H + lam*diag(H) (+1e-12 on camera
+    diagonals), identity for blocks without Jacobian rows, Schur complement on the landmarks."""
+    Hcc, Hpp, Hcp, g = ne["Hcc"], ne["Hpp"], ne["Hcp"], ne["g"]
+    gc, gp = g[:6 * F].reshape(F, 6), g[6 * F:].reshape(P, 3)
+    Dc = Hcc + lam * np.einsum("fij,ij->fij", Hcc, np.eye(6)) + 1e-12 * np.eye(6)
+    Dp = Hpp + lam * np.einsum("pij,ij->pij", Hpp, np.eye(3))
+    dead_p = np.abs(Hpp).sum(axis=(1, 2)) == 0
+    dead_c = np.abs(Hcc).sum(axis=(1, 2)) == 0
+    Dp[dead_p] = np.eye(3)
+    Dc[dead_c] = np.eye(6)
+    Dp_inv = np.linalg.inv(Dp)
+    E = np.zeros((P, F, 6, 3))
+    np.add.at(E, (pi, ci), Hcp)
+    T = np.einsum("pcij,pjk->pcik", E, Dp_inv)
+    Sb = -np.einsum("pcik,pdjk->cdij", T, E)
+    Sb[np.arange(F), np.arange(F)] += Dc
+    S = Sb.transpose(0, 2, 1, 3).reshape(6 * F, 6 * F)
+    rhs = -gc + np.einsum("pcik,pk->ci", T, gp)
+    dc = np.linalg.solve(S, rhs.ravel()).reshape(F, 6)
+    dc[dead_c] = 0
+    back = -gp.copy()
+    np.subtract.at(back, pi, np.einsum("oji,oj->oi", Hcp, dc[ci]))
+    dp = np.einsum("pij,pj->pi", Dp_inv, back)
+    dp[dead_p] = 0
+    return x + np.hstack([dc.ravel(), dp.ravel()])
+
+
+def _start(F, ci):
+    return int(np.count_nonzero(ci < int(F / 4) + 1))
+
+
+# 6 cameras: reduced system in LDS; 16: LDS beyond the default 64 KB; 26: reduced system kept in global memory
+@pytest.mark.parametrize("F,P,vis", [(6, 150, 0.7), (16, 300, 0.5), (26, 200, 0.4)])
+def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis):
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=F, P=P, visibility=vis, seed=F, obs_noise=0.4)
+    ci, pi, K = pb["ci"], pb["pi"], pb["K"]
+    obs = pb["obs"].astype(np.float64)
+    start = _start(F, ci)
+    x = pb["x"]
+    ne = oracle.ba_normal_eq(x, F, P, ci, pi, obs, K, start)
+    solver = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+    cost = solver.linearize(x)
+    assert abs(cost - float(ne["cost"])) <= 1e-10 * float(ne["cost"])
+    np.testing.assert_array_equal(solver.params(), x)
+    for lam in (1e-3, 1.0):
+        want = numpy_lm_step(ne, x, F, P, ci, pi, lam)
+        cost_new, solved = solver.try_step(lam)
+        assert solved
+        got = solver.params(candidate=True)
+        step = np.abs(want - x).max()
+        assert np.abs(got - want).max() <= 1e-7 * max(step, 1e-12) + 1e-12
+        ref_cost = float(oracle.ba_residual(want, F, P, ci, pi, obs, K)[1])
+        assert abs(cost_new - ref_cost) <= 1e-8 * ref_cost
+        # frozen cameras do not move
+        nf = int(F / 4) + 1
+        np.testing.assert_array_equal(got[:6 * nf], x[:6 * nf])
+    # accepting the candidate makes it the current point; the next step starts from there
+    solver.accept()
+    x1 = solver.params()
+    np.testing.assert_array_equal(x1, got)
+    ne1 = oracle.ba_normal_eq(x1, F, P, ci, pi, obs, K, start)
+    want2 = numpy_lm_step(ne1, x1, F, P, ci, pi, 1e-2)
+    solver.try_step(1e-2)
+    got2 = solver.params(candidate=True)
+    assert np.abs(got2 - want2).max() <= 1e-7 * max(np.abs(want2 - x1).max(), 1e-12) + 1e-12
+    solver.close()
+
+
+def test_device_inputs_and_unseen_landmarks(oracle, ctx):
+    import torch
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=5, P=80, visibility=0.6, seed=2)
+    F, P, K = pb["F"], pb["P"] + 7, pb["K"]                       # 7 landmarks nobody observes
+    ci, pi, obs = pb["ci"], pb["pi"], pb["obs"].astype(np.float64)
+    x = np.hstack([pb["x"], np.arange(21, dtype=np.float64)])
+    start = _start(F, ci)
+    dev = torch.device("cuda", 0)
+    a = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+    b = hip.BaSolver(ctx, F, P, torch.from_numpy(ci).to(dev), torch.from_numpy(pi).to(dev), torch.from_numpy(obs).to(dev), K, start)
+    ca, cb = a.linearize(x), b.linearize(torch.from_numpy(x).to(dev))
+    assert ca == pytest.approx(cb, rel=1e-12)
+    (na, sa), (nb, sb) = a.try_step(1e-3), b.try_step(1e-3)
+    assert sa and sb and na == pytest.approx(nb, rel=1e-9)
+    xa, xb = a.params(True), b.params(True)
+    np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(xa[-21:], x[-21:])              # unseen landmarks keep their coordinates
+    want = numpy_lm_step(oracle.ba_normal_eq(x, F, P, ci, pi, obs, K, start), x, F, P, ci, pi, 1e-3)
+    assert np.abs(xa - want).max() <= 1e-7 * np.abs(want - x).max()
+    assert na < ca
+
+
+def test_empty_window_state_errors_and_bad_indices(ctx):
+    from visual_odometry_amd import hip
+    from visual_odometry_amd._lib import VoError
+    K = synth.K_KITTI
+    e = hip.BaSolver(ctx, 2, 3, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 2)), K, 0)
+    x = np.arange(21, dtype=np.float64)
+    with pytest.raises(VoError):
+        e.try_step(1e-3)                                           # nothing linearised yet
+    assert e.linearize(x) == 0.0
+    with pytest.raises(VoError):
+        e.accept()                                                 # no candidate yet
+    cost, solved = e.try_step(1e-3)
+    assert cost == 0.0 and solved
+    np.testing.assert_array_equal(e.params(True), x)
+    with pytest.raises(ValueError):
+        e.linearize(x[:-1])
+    with pytest.raises(ValueError):
+        hip.BaSolver(ctx, 2, 3, np.array([0, 2]), np.array([0, 1]), np.zeros((2, 2)), K, 0)   # camera 2 of 2
+    with pytest.raises(ValueError):
+        hip.BaSolver(ctx, 2, 3, np.array([0, 1]), np.array([0, 1, 2]), np.zeros((2, 2)), K, 0)

@@ -86,6 +86,19 @@ def main():
     out.append({"op": "ba_residual", "workload": f"{O} observations", "ms": ms,
                 "reference_numpy_fun_ms_build_container": 16.9})
 
+    solver = hip.BaSolver(ctx, F, P, tci, tpi, tobs, pb["K"], start)
+    solver.linearize(tx)
+    for _ in range(3):
+        solver.try_step(1e-3)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        solver.try_step(1e-3)
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    out.append({"op": "ba_try_step", "workload": f"one LM trial step (Schur + Cholesky {6 * F}x{6 * F} + back-substitution + "
+                f"re-linearisation), {F} keyframes x {P} landmarks, {O} observations; host wall time incl. the cost read-back",
+                "ms": ms})
+    solver.close()
+
     # ---- config 2a: Harris / Shi-Tomasi + NMS top-2000 ------------------------
     B = 64
     img = synth.frame_pair(synth.KITTI_SHAPE, seed=2021)[0]

@@ -16,6 +16,7 @@
 // store); camera blocks are reduced across the wave with DPP before one atomic
 // per wave and entry, point blocks use per-lane float64 atomics.
 #include "vo_internal.h"
+#include <stdlib.h>
 
 #define BA_THREADS 256
 
@@ -296,4 +297,452 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 {
     return ba_common<true>(ctx, params, F, P, ci, pi, obs, O, K, obs_start, r, cost, Hcc, Hpp, Hcp, g, mem,
                            "vo_ba_normal_eq");
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident Levenberg-Marquardt state for one bundle-adjustment window.
+//
+// The reference solves the window with scipy's least_squares (trf + lsmr,
+// vo_pipeline/bundleAdjustment.py:96-97).  Here a step is: Schur complement of
+// the landmark blocks (one wavefront per landmark), Cholesky solve of the
+// 6F x 6F reduced camera system in one workgroup, back-substitution (one lane
+// per landmark), then residual + normal equations at the candidate.  Current and
+// candidate linearisations are double-buffered, so accepting a step is a swap.
+// Damping: D = H + lambda * diag(H) (+1e-12 on camera diagonals); blocks that
+// received no Jacobian rows (frozen cameras, unseen landmarks) become identity
+// and their step is zero.
+// ---------------------------------------------------------------------------
+struct vo_ba {
+    vo_ctx *ctx = nullptr;
+    int F = 0, P = 0, O = 0, n = 0, obs_start = 0;
+    BaK K;
+    char *pool = nullptr;
+    int64_t *ci = nullptr, *pi = nullptr;
+    int *cam32 = nullptr, *pptr = nullptr, *pobs = nullptr, *flag = nullptr;
+    double *obs = nullptr, *r = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
+    double *x[2] = {nullptr, nullptr}, *cost[2] = {nullptr, nullptr}, *Hcc[2] = {nullptr, nullptr},
+           *Hpp[2] = {nullptr, nullptr}, *Hcp[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};
+    int cur = 0;
+    bool linearized = false, have_candidate = false;
+    size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
+};
+
+#define SCHUR_THREADS 1024
+#define SOLVE_THREADS 256
+
+__device__ __forceinline__ void damped_point_inverse(const double *__restrict__ H, double lambda, double *inv, bool &dead)
+{
+    double a[9];
+    double sabs = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a[k] = H[k]; sabs += fabs(a[k]); }
+    dead = sabs == 0;
+    if (dead) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) inv[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    a[0] += lambda * a[0]; a[4] += lambda * a[4]; a[8] += lambda * a[8];
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const double id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = (a[2] * a[7] - a[1] * a[8]) * id; inv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    inv[3] = c01 * id; inv[4] = (a[0] * a[8] - a[2] * a[6]) * id; inv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    inv[6] = c02 * id; inv[7] = (a[1] * a[6] - a[0] * a[7]) * id; inv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+// S -= sum_p E_p Dp^-1 E_p^T, rhs += sum_p E_p Dp^-1 g_p with E_p the Hcp blocks of
+// landmark p's observations.  One wavefront per landmark (grid-stride).  A lane owns
+// one column of the reduced system, (observation b, row j of its block): it keeps
+// z = Dp^-1 Hcp_b[j,:]^T, and for every observation a of the landmark (wave-uniform,
+// so Hcp_a comes through scalar loads) adds the six entries Hcp_a[i,:] . z.  With LDS
+// the workgroup sums into a private copy of the reduced system first.
+template <bool LDS>
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, int F, const int *__restrict__ pptr,
+                                                                 const int *__restrict__ pobs, const int *__restrict__ cam,
+                                                                 const double *__restrict__ Hpp, const double *__restrict__ Hcp,
+                                                                 const double *__restrict__ g, double lambda,
+                                                                 double *__restrict__ Dpinv, double *__restrict__ S,
+                                                                 double *__restrict__ rhs)
+{
+    extern __shared__ double sl[];
+    double *Sa = LDS ? sl : S, *ra = LDS ? sl + (size_t)n * n : rhs;
+    if (LDS) {
+        for (int i = threadIdx.x; i < n * n + n; i += SCHUR_THREADS) sl[i] = 0.0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int waves = SCHUR_THREADS / 64;
+    for (int p = blockIdx.x * waves + (threadIdx.x >> 6); p < P; p += gridDim.x * waves) {
+        double inv[9];
+        bool dead;
+        damped_point_inverse(Hpp + 9 * (int64_t)p, lambda, inv, dead);
+        if (lane < 9) Dpinv[9 * (int64_t)p + lane] = inv[lane];
+        if (dead) continue;  // no Jacobian rows: every Hcp block of this landmark is zero
+        const int o0 = pptr[p], k = pptr[p + 1] - o0;
+        const double *gp = g + 6 * (int64_t)F + 3 * (int64_t)p;
+        const double u0 = inv[0] * gp[0] + inv[1] * gp[1] + inv[2] * gp[2];
+        const double u1 = inv[3] * gp[0] + inv[4] * gp[1] + inv[5] * gp[2];
+        const double u2 = inv[6] * gp[0] + inv[7] * gp[1] + inv[8] * gp[2];
+        for (int t0 = 0; t0 < 6 * k; t0 += 64) {
+            const int t = t0 + lane;
+            const bool on = t < 6 * k;
+            const int b = on ? t / 6 : 0, j = on ? t - 6 * b : 0;
+            const int ob = pobs[o0 + b];
+            const double *y = Hcp + 18 * (int64_t)ob + 3 * j;
+            const double y0 = y[0], y1 = y[1], y2 = y[2];
+            const int col = 6 * cam[ob] + j;
+            if (on) unsafeAtomicAdd(ra + col, y0 * u0 + y1 * u1 + y2 * u2);
+            const double z0 = inv[0] * y0 + inv[1] * y1 + inv[2] * y2;
+            const double z1 = inv[3] * y0 + inv[4] * y1 + inv[5] * y2;
+            const double z2 = inv[6] * y0 + inv[7] * y1 + inv[8] * y2;
+            for (int a = 0; a < k; ++a) {
+                const int oa = __builtin_amdgcn_readfirstlane(pobs[o0 + a]);
+                const double *x = Hcp + 18 * (int64_t)oa;
+                double *dst = Sa + (size_t)(6 * __builtin_amdgcn_readfirstlane(cam[oa])) * n + col;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double v = x[3 * i] * z0 + x[3 * i + 1] * z1 + x[3 * i + 2] * z2;
+                    if (on && v != 0.0) unsafeAtomicAdd(dst + (size_t)i * n, -v);
+                }
+            }
+        }
+    }
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * n; i += SCHUR_THREADS)
+            if (sl[i] != 0.0) unsafeAtomicAdd(S + i, sl[i]);
+        for (int i = threadIdx.x; i < n; i += SCHUR_THREADS)
+            if (sl[(size_t)n * n + i] != 0.0) unsafeAtomicAdd(rhs + i, sl[(size_t)n * n + i]);
+    }
+}
+
+// Adds the damped camera blocks, then solves S dc = rhs - g_c in one workgroup by a
+// square-root-free Cholesky (S = L D L^T).  Columns stay unscaled (c_ik = L_ik d_k) and
+// the right-hand side is eliminated along as an extra row, so a column step is one
+// rank-1 update and one barrier; back-substitution is one barrier per column.
+// flag[0] = 1 on success, 0 when a pivot is not positive.
+template <bool LDS>
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, double *__restrict__ S, double *__restrict__ rhs,
+                                                                 const double *__restrict__ Hcc, const double *__restrict__ g,
+                                                                 double lambda, double *__restrict__ dc, int *__restrict__ flag)
+{
+    extern __shared__ double sl[];
+    __shared__ int fail;
+    __shared__ unsigned char dead_cam[256];
+    double *A = LDS ? sl : S, *b = LDS ? sl + (size_t)n * n : rhs, *dinv = LDS ? sl + (size_t)n * n + n : dc;
+    const int tid = threadIdx.x;
+    if (tid == 0) fail = 0;
+    for (int c = tid; c < F; c += SOLVE_THREADS) {
+        double sabs = 0;
+        for (int k = 0; k < 36; ++k) sabs += fabs(Hcc[36 * (int64_t)c + k]);
+        dead_cam[c] = sabs == 0;
+    }
+    if (LDS) {
+        for (int i = tid; i < n * n; i += SOLVE_THREADS) A[i] = S[i];
+        for (int i = tid; i < n; i += SOLVE_THREADS) b[i] = rhs[i];
+    }
+    __syncthreads();
+    for (int t = tid; t < F * 36; t += SOLVE_THREADS) {
+        const int c = t / 36, e = t - c * 36, i = e / 6, j = e - i * 6;
+        const bool dead = dead_cam[c];
+        double v = Hcc[t];
+        if (i == j) v += lambda * v + 1e-12;
+        if (dead) v = (i == j) ? 1.0 : 0.0;
+        const size_t at = (size_t)(6 * c + i) * n + 6 * c + j;
+        A[at] = dead ? v : A[at] + v;
+    }
+    for (int i = tid; i < n; i += SOLVE_THREADS) b[i] -= g[i];
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int k = 0; k < n; ++k) {
+        const double d = A[(size_t)k * n + k];  // final since the previous step's barrier; same in every thread
+        if (!(d > 0.0)) {
+            if (tid == 0) fail = 1;
+            break;
+        }
+        const double id = 1.0 / d;
+        if (tid == 0) dinv[k] = id;
+        for (int i = k + 1 + ty; i <= n; i += 16) {  // row n is the right-hand side
+            const double f = (i < n ? A[(size_t)i * n + k] : b[k]) * id;
+            double *row = i < n ? A + (size_t)i * n : b;
+            const int jmax = i < n ? i : n - 1;
+            for (int j = k + 1 + tx; j <= jmax; j += 16) row[j] -= f * A[(size_t)j * n + k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (fail) {
+        __syncthreads();  // dinv may alias dc
+        if (tid == 0) flag[0] = 0;
+        for (int i = tid; i < n; i += SOLVE_THREADS) dc[i] = 0.0;
+        return;
+    }
+    // b holds z = L^-1 rhs; y = D^-1 z; L^T x = y
+    for (int i = tid; i < n; i += SOLVE_THREADS) b[i] *= dinv[i];
+    __syncthreads();
+    for (int k = n - 1; k > 0; --k) {
+        const double xk = b[k];
+        for (int i = tid; i < k; i += SOLVE_THREADS) b[i] -= A[(size_t)k * n + i] * dinv[i] * xk;
+        __syncthreads();
+    }
+    double out[(256 * 6 + SOLVE_THREADS - 1) / SOLVE_THREADS];
+    int m = 0;
+    for (int i = tid; i < n; i += SOLVE_THREADS) out[m++] = dead_cam[i / 6] ? 0.0 : b[i];
+    __syncthreads();  // every read of dinv (possibly aliasing dc) is done
+    m = 0;
+    for (int i = tid; i < n; i += SOLVE_THREADS) dc[i] = out[m++];
+    if (tid == 0) flag[0] = 1;
+}
+
+// dp = Dp^-1 (-g_p - sum_obs Hcp^T dc[camera]); candidate = current + (dc, dp).
+__global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, const int *__restrict__ pptr,
+                                                         const int *__restrict__ pobs, const int *__restrict__ cam,
+                                                         const double *__restrict__ Hpp, const double *__restrict__ Hcp,
+                                                         const double *__restrict__ g, const double *__restrict__ Dpinv,
+                                                         const double *__restrict__ dc, const double *__restrict__ x,
+                                                         double *__restrict__ x_new)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n) x_new[p] = x[p] + dc[p];
+    if (p >= P) return;
+    double sabs = 0;
+    for (int k = 0; k < 9; ++k) sabs += fabs(Hpp[9 * (int64_t)p + k]);
+    const int64_t at = 6 * (int64_t)F + 3 * (int64_t)p;
+    double d[3] = {0, 0, 0};
+    if (sabs != 0) {
+        double bk[3] = {-g[at], -g[at + 1], -g[at + 2]};
+        for (int o = pptr[p]; o < pptr[p + 1]; ++o) {
+            const int ob = pobs[o];
+            const double *h = Hcp + 18 * (int64_t)ob, *q = dc + 6 * cam[ob];
+            for (int a = 0; a < 6; ++a) {
+                bk[0] -= h[3 * a] * q[a];
+                bk[1] -= h[3 * a + 1] * q[a];
+                bk[2] -= h[3 * a + 2] * q[a];
+            }
+        }
+        const double *iv = Dpinv + 9 * (int64_t)p;
+        for (int a = 0; a < 3; ++a) d[a] = iv[3 * a] * bk[0] + iv[3 * a + 1] * bk[1] + iv[3 * a + 2] * bk[2];
+    }
+    for (int a = 0; a < 3; ++a) x_new[at + a] = x[at + a] + d[a];
+}
+
+static int ba_linearize_into(vo_ba *ba, int slot)
+{
+    vo_ctx *ctx = ba->ctx;
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
+    VO_HIP_CHECK(hipMemsetAsync(ba->cost[slot], 0, 8, ctx->stream));
+    if (ba->F) VO_HIP_CHECK(hipMemsetAsync(ba->Hcc[slot], 0, (size_t)ba->F * 288, ctx->stream));
+    if (ba->P) VO_HIP_CHECK(hipMemsetAsync(ba->Hpp[slot], 0, (size_t)ba->P * 72, ctx->stream));
+    if (np_) VO_HIP_CHECK(hipMemsetAsync(ba->g[slot], 0, np_ * 8, ctx->stream));
+    if (ba->O) {
+        const unsigned blocks = (unsigned)((ba->O + BA_THREADS - 1) / BA_THREADS);
+        hipLaunchKernelGGL(ba_kernel<true>, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P, ba->ci,
+                           ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot], ba->Hpp[slot],
+                           ba->Hcp[slot], ba->g[slot]);
+        VO_HIP_CHECK(hipGetLastError());
+    }
+    return VO_OK;
+}
+
+extern "C" void vo_ba_destroy(vo_ba *ba)
+{
+    if (!ba) return;
+    if (ba->pool && vo_ctx_is_live(ba->ctx)) {
+        (void)hipSetDevice(ba->ctx->device);
+        (void)hipStreamSynchronize(ba->ctx->stream);
+        (void)hipFree(ba->pool);
+    }
+    delete ba;
+}
+
+extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const double *obs,
+                            const double *K, int obs_start, int mem, vo_ba **out)
+{
+    VO_REQUIRE(ctx && out && K, "vo_ba_create: NULL argument");
+    *out = nullptr;
+    VO_REQUIRE(F >= 1 && P >= 1 && O >= 0, "vo_ba_create: F=%d P=%d O=%d", F, P, O);
+    VO_REQUIRE(F <= 256, "vo_ba_create: at most 256 cameras per window (F=%d)", F);
+    VO_REQUIRE(obs_start >= 0, "vo_ba_create: obs_start=%d", obs_start);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_create: bad mem flag %d", mem);
+    VO_REQUIRE(O == 0 || (ci && pi && obs), "vo_ba_create: NULL observation buffers");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    // host copies of the index arrays: range check and landmark-major observation lists
+    int64_t *hci = nullptr, *hpi = nullptr;
+    const int64_t *sci = ci, *spi = pi;
+    if (mem == VO_MEM_DEVICE && O) {
+        hci = (int64_t *)malloc((size_t)O * 8);
+        hpi = (int64_t *)malloc((size_t)O * 8);
+        if (!hci || !hpi) { free(hci); free(hpi); vo_set_error("vo_ba_create: out of host memory"); return VO_ENOMEM; }
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(hci, ci, (size_t)O * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hpi, pi, (size_t)O * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(hci); free(hpi); vo_set_error("vo_ba_create: index download failed: %s", hipGetErrorString(e)); return VO_EHIP; }
+        sci = hci; spi = hpi;
+    }
+    int *cam32 = (int *)malloc(((size_t)O + 1) * 4), *pptr = (int *)calloc((size_t)P + 2, 4), *pobs = (int *)malloc(((size_t)O + 1) * 4);
+    int rc = VO_OK;
+    if (!cam32 || !pptr || !pobs) { rc = VO_ENOMEM; vo_set_error("vo_ba_create: out of host memory"); }
+    for (int i = 0; rc == VO_OK && i < O; ++i) {
+        if (sci[i] < 0 || sci[i] >= F || spi[i] < 0 || spi[i] >= P) {
+            vo_set_error("vo_ba_create: observation %d has index out of range (camera %lld, point %lld)", i, (long long)sci[i],
+                         (long long)spi[i]);
+            rc = VO_EINVAL;
+        }
+    }
+    vo_ba *ba = nullptr;
+    if (rc == VO_OK) {
+        for (int i = 0; i < O; ++i) { cam32[i] = (int)sci[i]; pptr[spi[i] + 1]++; }
+        for (int p = 0; p < P; ++p) pptr[p + 1] += pptr[p];
+        int *fill = (int *)malloc(((size_t)P + 1) * 4);
+        if (!fill) { rc = VO_ENOMEM; vo_set_error("vo_ba_create: out of host memory"); }
+        else {
+            memcpy(fill, pptr, ((size_t)P + 1) * 4);
+            for (int i = 0; i < O; ++i) pobs[fill[spi[i]]++] = i;
+            free(fill);
+        }
+    }
+    if (rc == VO_OK) {
+        ba = new vo_ba();
+        ba->ctx = ctx; ba->F = F; ba->P = P; ba->O = O; ba->n = 6 * F; ba->obs_start = obs_start;
+        memcpy(ba->K.k, K, sizeof(ba->K.k));
+        const size_t n = (size_t)ba->n, np_ = n + 3 * (size_t)P, Oz = (size_t)(O ? O : 1);
+        // pool layout
+        size_t tot = 0;
+        auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
+        const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
+                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16),
+                     o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8);
+        size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
+        for (int s = 0; s < 2; ++s) {
+            o_x[s] = take(np_ * 8); o_cost[s] = take(8); o_Hcc[s] = take((size_t)F * 288); o_Hpp[s] = take((size_t)P * 72);
+            o_Hcp[s] = take(Oz * 144); o_g[s] = take(np_ * 8);
+        }
+        hipError_t e = hipMalloc((void **)&ba->pool, tot);
+        if (e != hipSuccess) {
+            vo_set_error("vo_ba_create: hipMalloc(%zu) failed: %s", tot, hipGetErrorString(e));
+            delete ba; ba = nullptr; rc = VO_ENOMEM;
+        } else {
+            char *b = ba->pool;
+            ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
+            ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
+            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Dpinv = (double *)(b + o_dpi);
+            ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
+            for (int s = 0; s < 2; ++s) {
+                ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
+                ba->Hpp[s] = (double *)(b + o_Hpp[s]); ba->Hcp[s] = (double *)(b + o_Hcp[s]); ba->g[s] = (double *)(b + o_g[s]);
+            }
+            const hipMemcpyKind kind = mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+            e = hipSuccess;
+            if (O) {
+                e = hipMemcpy(ba->ci, sci, (size_t)O * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(ba->pi, spi, (size_t)O * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(ba->cam32, cam32, (size_t)O * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(ba->pobs, pobs, (size_t)O * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(ba->obs, obs, (size_t)O * 16, kind);
+            }
+            if (e == hipSuccess) e = hipMemcpy(ba->pptr, pptr, ((size_t)P + 1) * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                vo_set_error("vo_ba_create: upload failed: %s", hipGetErrorString(e));
+                (void)hipFree(ba->pool); delete ba; ba = nullptr; rc = VO_EHIP;
+            }
+        }
+        if (ba) {
+            // keep the reduced system in LDS when it fits (up to the 160 KB of a gfx950 CU)
+            const size_t need = (n * n + 2 * n) * 8;
+            ba->lds_bytes = 0;
+            if (need <= 60 * 1024) ba->lds_bytes = need;
+            else if (need + 1024 <= 160 * 1024 &&
+                     hipFuncSetAttribute((const void *)ba_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess &&
+                     hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
+                ba->lds_bytes = need;
+            (void)hipGetLastError();
+        }
+    }
+    free(hci); free(hpi); free(cam32); free(pptr); free(pobs);
+    *out = ba;
+    return rc;
+}
+
+extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost)
+{
+    VO_REQUIRE(ctx && ba && x && cost, "vo_ba_linearize: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_linearize: solver belongs to another context");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_linearize: bad mem flag %d", mem);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
+    VO_HIP_CHECK(hipMemcpyAsync(ba->x[ba->cur], x, np_ * 8, mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                ctx->stream));
+    int rc = ba_linearize_into(ba, ba->cur);
+    if (rc) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(cost, ba->cost[ba->cur], 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ba->linearized = true;
+    ba->have_candidate = false;
+    return VO_OK;
+}
+
+extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved)
+{
+    VO_REQUIRE(ctx && ba && cost_new && solved, "vo_ba_try_step: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_try_step: solver belongs to another context");
+    VO_REQUIRE(lambda >= 0, "vo_ba_try_step: lambda=%g", lambda);
+    if (!ba->linearized) { vo_set_error("vo_ba_try_step: call vo_ba_linearize first"); return VO_ESTATE; }
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const int c = ba->cur, o = 1 - c, n = ba->n;
+    VO_HIP_CHECK(hipMemsetAsync(ba->S, 0, ((size_t)n * n + 0) * 8, ctx->stream));
+    VO_HIP_CHECK(hipMemsetAsync(ba->rhs, 0, (size_t)n * 8, ctx->stream));
+    const int waves = SCHUR_THREADS / 64;
+    int blocks = (ba->P + waves - 1) / waves;
+    if (blocks > 128) blocks = 128;
+    if (ba->lds_bytes)
+        hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(blocks), dim3(SCHUR_THREADS), ba->lds_bytes, ctx->stream, n, ba->P, ba->F,
+                           ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
+    else
+        hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(blocks), dim3(SCHUR_THREADS), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
+                           ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
+    VO_HIP_CHECK(hipGetLastError());
+    if (ba->lds_bytes)
+        hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
+                           ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+    else
+        hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
+                           ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+    VO_HIP_CHECK(hipGetLastError());
+    const int work = ba->P > n ? ba->P : n;
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
+                       ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], ba->Dpinv, ba->dc, ba->x[c], ba->x[o]);
+    VO_HIP_CHECK(hipGetLastError());
+    int rc = ba_linearize_into(ba, o);
+    if (rc) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(cost_new, ba->cost[o], 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(solved, ba->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ba->have_candidate = true;
+    return VO_OK;
+}
+
+extern "C" int vo_ba_accept(vo_ctx *ctx, vo_ba *ba)
+{
+    VO_REQUIRE(ctx && ba, "vo_ba_accept: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_accept: solver belongs to another context");
+    if (!ba->have_candidate) { vo_set_error("vo_ba_accept: no candidate step (call vo_ba_try_step first)"); return VO_ESTATE; }
+    ba->cur = 1 - ba->cur;
+    ba->have_candidate = false;
+    return VO_OK;
+}
+
+extern "C" int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, int mem)
+{
+    VO_REQUIRE(ctx && ba && x, "vo_ba_params: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_params: solver belongs to another context");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_params: bad mem flag %d", mem);
+    if (!ba->linearized || (candidate && !ba->have_candidate)) { vo_set_error("vo_ba_params: nothing to return yet"); return VO_ESTATE; }
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
+    const int slot = candidate ? 1 - ba->cur : ba->cur;
+    VO_HIP_CHECK(hipMemcpyAsync(x, ba->x[slot], np_ * 8, mem == VO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                ctx->stream));
+    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
 }

@@ -77,10 +77,10 @@ _default_ctx = {}
 
 @atexit.register
 def _shutdown():
-    """Destroy pyramids before contexts, while the HIP runtime is still up."""
+    """Destroy pyramids and solvers before contexts, while the HIP runtime is still up."""
     objs = list(_live_objects)
     for o in objs:
-        if isinstance(o, Pyramid):
+        if isinstance(o, (Pyramid, BaSolver)):
             o.close()
     for o in objs:
         if isinstance(o, Context):
@@ -434,3 +434,78 @@ def triangulate(ctx: Context, pts1, pts2, M1, M2):
     check(ctx.lib.vo_triangulate(ctx.handle, _ptr(pts1), _ptr(pts2), int(pts1.shape[0]), A.ctypes.data_as(_lib.c_f64p),
                                  B.ctypes.data_as(_lib.c_f64p), int(f1), int(f2), _ptr(out), mem), "vo_triangulate")
     return out
+
+
+class BaSolver:
+    """Device-resident Levenberg-Marquardt state of one bundle-adjustment window (vo_ba_*).
+    ci, pi, obs may be numpy arrays or torch tensors on the context's device; K is host."""
+
+    def __init__(self, ctx: Context, F: int, P: int, ci, pi, obs, K, obs_start: int = 0):
+        self.ctx, self.F, self.P = ctx, int(F), int(P)
+        self.handle = None
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        if _is_torch(ci):
+            import torch
+            if not (_is_torch(pi) and _is_torch(obs)):
+                raise ValueError("BaSolver: ci, pi, obs must live in the same memory")
+            if ci.dtype != torch.int64 or pi.dtype != torch.int64 or obs.dtype != torch.float64:
+                raise ValueError("BaSolver: device inputs must be int64 indices and float64 observations")
+            ci, pi, obs = ci.contiguous(), pi.contiguous(), obs.contiguous()
+            O, mem = int(ci.numel()), VO_MEM_DEVICE
+        else:
+            ci = np.ascontiguousarray(ci, np.int64).ravel()
+            pi = np.ascontiguousarray(pi, np.int64).ravel()
+            obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+            O, mem = int(ci.size), VO_MEM_HOST
+        if int(pi.shape[0] if not _is_torch(pi) else pi.numel()) != O or int(obs.shape[0]) != O:
+            raise ValueError("BaSolver: ci, pi and obs differ in length")
+        self.O = O
+        h = ctypes.c_void_p()
+        check(ctx.lib.vo_ba_create(ctx.handle, self.F, self.P, O, _ptr(ci), _ptr(pi), _ptr(obs), Kd.ctypes.data_as(_lib.c_f64p),
+                                   int(obs_start), mem, ctypes.byref(h)), "vo_ba_create")
+        self.handle = h
+        _live_objects.add(self)
+
+    def linearize(self, x) -> float:
+        """Set the current parameter vector (6F+3P float64) and build residual + normal equations; returns the cost."""
+        cost = ctypes.c_double()
+        if _is_torch(x):
+            x = x.contiguous()
+            mem = VO_MEM_DEVICE
+            n = int(x.numel())
+        else:
+            x = np.ascontiguousarray(x, np.float64).ravel()
+            mem = VO_MEM_HOST
+            n = int(x.size)
+        if n != 6 * self.F + 3 * self.P:
+            raise ValueError(f"BaSolver.linearize: parameter vector has {n} entries, expected {6 * self.F + 3 * self.P}")
+        check(self.ctx.lib.vo_ba_linearize(self.ctx.handle, self.handle, _ptr(x), mem, ctypes.byref(cost)), "vo_ba_linearize")
+        return cost.value
+
+    def try_step(self, lam: float) -> Tuple[float, bool]:
+        """Candidate = current + LM step for damping lam -> (cost at the candidate, reduced system solved)."""
+        cost, ok = ctypes.c_double(), ctypes.c_int()
+        check(self.ctx.lib.vo_ba_try_step(self.ctx.handle, self.handle, float(lam), ctypes.byref(cost), ctypes.byref(ok)),
+              "vo_ba_try_step")
+        return cost.value, bool(ok.value)
+
+    def accept(self) -> None:
+        check(self.ctx.lib.vo_ba_accept(self.ctx.handle, self.handle), "vo_ba_accept")
+
+    def params(self, candidate: bool = False) -> np.ndarray:
+        x = np.empty(6 * self.F + 3 * self.P, np.float64)
+        check(self.ctx.lib.vo_ba_params(self.ctx.handle, self.handle, int(candidate), _ptr(x), VO_MEM_HOST), "vo_ba_params")
+        return x
+
+    def close(self) -> None:
+        if self.handle:
+            self.ctx.lib.vo_ba_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass

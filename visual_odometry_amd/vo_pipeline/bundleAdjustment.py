@@ -4,10 +4,10 @@ _fun / _reproject / _rotate evaluate on the GPU (vo_ba_residual).  The solve kee
 the reference's problem definition -- outlier pre-filter, parameter vector
 [F x (rvec, t) | P x XYZ], first int(F/4)+1 cameras and their observation rows
 frozen, cost 0.5*|r|^2, ftol 1e-4 -- but where the reference hands scipy's TRF a
-finite-difference Jacobian, this uses the analytic normal equations from the GPU
-(vo_ba_normal_eq) in a Levenberg-Marquardt loop with a Schur complement on the
-landmarks.  Iterates therefore differ from scipy's; the residual, cost and
-Jacobian at a given x are the same.
+finite-difference Jacobian, this runs Levenberg-Marquardt on the analytic normal
+equations with a Schur complement on the landmarks, all on the GPU (vo_ba_create /
+vo_ba_try_step / vo_ba_accept).  Iterates therefore differ from scipy's; the
+residual, cost and Jacobian at a given x are the same.
 """
 from typing import Tuple
 
@@ -132,53 +132,28 @@ class BundleAdjustment:
         return adjusted_M, x[6 * F:].reshape(landmarks.shape).copy()
 
     def _levenberg_marquardt(self, x, F, P, ci, pi, obs, start, max_iters, ftol):
-        ctx = _runtime.context()
-        O = ci.size
-        if O == 0:
+        """LM loop on the device-resident solver: every trial step (Schur complement, reduced solve,
+        back-substitution, re-linearisation) runs on the GPU; the host only compares two costs."""
+        if ci.size == 0:
             return x
-        lam = 1e-3
-        ne = hip.ba_normal_eq(ctx, x, F, P, ci, pi, obs, self.K, start)
-        for _ in range(max_iters):
-            cost = ne["cost"]
-            Hcc, Hpp, Hcp, g = ne["Hcc"], ne["Hpp"], ne["Hcp"], ne["g"]
-            gc, gp = g[:6 * F].reshape(F, 6), g[6 * F:].reshape(P, 3)
-            improved = False
-            for _try in range(10):
-                # damped blocks; parameters without Jacobian rows (frozen cameras, unseen points) get identity
-                Dc = Hcc + lam * np.einsum("fij,ij->fij", Hcc, np.eye(6)) + 1e-12 * np.eye(6)
-                Dp = Hpp + lam * np.einsum("pij,ij->pij", Hpp, np.eye(3))
-                dead_p = np.abs(Hpp).sum(axis=(1, 2)) == 0
-                Dp[dead_p] = np.eye(3)
-                dead_c = np.abs(Hcc).sum(axis=(1, 2)) == 0
-                Dc[dead_c] = np.eye(6)
-                Dp_inv = np.linalg.inv(Dp)
-                # Schur complement on the landmarks: S = Dc - sum_p E_p Dp^-1 E_p^T with
-                # E[p, c] = Hcp of the observation of point p in camera c
-                E = np.zeros((P, F, 6, 3))
-                np.add.at(E, (pi, ci), Hcp)
-                T = np.einsum("pcij,pjk->pcik", E, Dp_inv)
-                Sb = -np.einsum("pcik,pdjk->cdij", T, E)
-                Sb[np.arange(F), np.arange(F)] += Dc
-                S = Sb.transpose(0, 2, 1, 3).reshape(6 * F, 6 * F)
-                rhs = -gc + np.einsum("pcik,pk->ci", T, gp)
-                try:
-                    dc = np.linalg.solve(S, rhs.ravel()).reshape(F, 6)
-                except np.linalg.LinAlgError:
+        solver = hip.BaSolver(_runtime.context(), F, P, ci, pi, obs, self.K, start)
+        try:
+            cost = solver.linearize(x)
+            lam = 1e-3
+            for _ in range(max_iters):
+                improved = False
+                prev = cost
+                for _try in range(10):
+                    cost_new, solved = solver.try_step(lam)
+                    if solved and np.isfinite(cost_new) and cost_new < cost:
+                        solver.accept()
+                        cost = cost_new
+                        lam = max(lam / 3, 1e-9)
+                        improved = True
+                        break
                     lam *= 10
-                    continue
-                dc[dead_c] = 0
-                back = -gp.copy()
-                np.subtract.at(back, pi, np.einsum("oji,oj->oi", Hcp, dc[ci]))
-                dp = np.einsum("pij,pj->pi", Dp_inv, back)
-                dp[dead_p] = 0
-                x_new = x + np.hstack([dc.ravel(), dp.ravel()])
-                ne_new = hip.ba_normal_eq(ctx, x_new, F, P, ci, pi, obs, self.K, start)
-                if np.isfinite(ne_new["cost"]) and ne_new["cost"] < cost:
-                    x, ne = x_new, ne_new
-                    lam = max(lam / 3, 1e-9)
-                    improved = True
+                if not improved or (prev - cost) < ftol * prev:
                     break
-                lam *= 10
-            if not improved or (cost - ne["cost"]) < ftol * cost:
-                break
-        return x
+            return solver.params()
+        finally:
+            solver.close()
