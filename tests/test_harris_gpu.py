@@ -22,7 +22,8 @@ def test_response_bit_exact(oracle, ctx, shape, mode):
 
 
 @pytest.mark.parametrize("shape,K,radius", [((60, 83), 50, 1), ((376, 1241), 2000, 5), ((376, 1241), 4096, 1),
-                                           ((480, 640), 300, 8), ((40, 40), 4096, 1)])
+                                           ((480, 640), 300, 8), ((40, 40), 4096, 1),
+                                           ((200, 333), 500, 12), ((150, 170), 64, 32), ((33, 70), 100, 3)])
 def test_nms_topk_identical(oracle, ctx, shape, K, radius):
     from visual_odometry_amd import hip
     imgs = np.stack([synth.frame_pair(shape, seed=s)[0] for s in (1, 2)])
@@ -43,6 +44,17 @@ def test_nms_ties_and_flat(oracle, ctx):
     rxy, rsc, m = oracle.nms_topk(R[0], 8, 0.01, 1)
     assert cnt[0] == m == 3
     np.testing.assert_array_equal(xy[0], rxy)
+    # equal values inside one window, in the same row, in earlier rows and across a tile seam (x = 63|64)
+    T = np.zeros((1, 40, 140), np.float32)
+    for (y, x) in [(8, 8), (8, 11), (12, 62), (10, 66), (30, 100), (33, 97), (20, 30)]:
+        T[0, y, x] = 5
+    T[0, 20, 30] = 6
+    for radius in (2, 4, 5, 9):
+        xy, sc, cnt = hip.nms_topk(ctx, T, 16, 0.01, radius)
+        rxy, rsc, m = oracle.nms_topk(T[0], 16, 0.01, radius)
+        assert cnt[0] == m
+        np.testing.assert_array_equal(xy[0], rxy)
+        np.testing.assert_array_equal(sc[0], rsc)
     flat = np.zeros((1, 16, 16), np.float32)
     xy, sc, cnt = hip.nms_topk(ctx, flat, 4, 0.01, 1)
     assert cnt[0] == 0 and (xy == 0).all()

@@ -9,11 +9,12 @@
 // derivative tile from it and emits 8x32 responses; image bytes are read once
 // from HBM per tile (+halo), the response is written once.
 //
-// NMS/top-K: per image (1) max reduction, (2) strict local maxima above
-// rel_thresh*max in a (2r+1)^2 window are appended as 64-bit keys
-// {ordered(response), ~raster index}, (3) one workgroup radix-selects the K-th
-// largest key, gathers the K winners into LDS, bitonic-sorts them and writes
-// (x, y) strongest first.  Keys are unique, so the output is deterministic.
+// NMS/top-K: per image (1) max reduction, (2) local maxima above rel_thresh*max
+// in a (2r+1)^2 window (separable running maximum over LDS tiles; ties go to the
+// earlier raster position) are stored as 64-bit keys {ordered(response), ~raster
+// index} in per-tile slots, (3) one workgroup radix-selects the K-th largest key,
+// gathers the K winners into LDS, bitonic-sorts them and writes (x, y) strongest
+// first.  Keys are unique, so the output is deterministic.
 #include "vo_internal.h"
 #include <limits.h>
 
@@ -130,100 +131,101 @@ __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ 
         atomicMax(&maxkey[blockIdx.y], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
 }
 
-// before/after rule of the suppression: an earlier raster neighbour wins ties
-__device__ __forceinline__ bool beaten(float q, float v, bool before) { return before ? (q >= v) : (q > v); }
+#define NMS_TW 64
+#define NMS_TH 16
 
-// Stage 1: pixels above the threshold that are maxima of their 3x3 neighbourhood.
-// radius == 1: they are final (written as 64-bit keys); else their raster indices
-// go to a per-image list for the full-window test.
-__global__ __launch_bounds__(256) void nms3x3_kernel(const float *__restrict__ R, int w, int h, float rel_thresh,
-                                                     const uint32_t *__restrict__ maxkey, int final_stage,
-                                                     unsigned long long *__restrict__ cand, int cap,
-                                                     uint32_t *__restrict__ list, int list_cap, int *__restrict__ counter)
+// Window non-maximum suppression in one pass over R.  A workgroup stages a 64x16
+// tile with a halo of `radius` pixels (outside the image: -inf) and takes the running
+// maximum along rows, then along columns, the rows above the centre separately.  A
+// pixel above the threshold survives when it equals its window maximum and every
+// earlier raster neighbour (rows above, left part of its own row) is strictly
+// smaller: an earlier neighbour wins ties.  Survivors leave as 64-bit keys
+// {ordered(R), ~raster index} in the tile's own slots of the candidate array
+// (survivors are more than `radius` apart, which bounds their number per tile; the
+// caller zero-fills the array and zero marks an empty slot).  RAD > 0 fixes the
+// radius at compile time (fully unrolled window loops); RAD == 0 takes it at run time.
+template <int RAD>
+__global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__ R, int w, int h, int radius, float rel_thresh,
+                                                       const uint32_t *__restrict__ maxkey,
+                                                       unsigned long long *__restrict__ cand, int tile_slots)
 {
-    __shared__ int s_n, s_base;
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    extern __shared__ float nms_lds[];
+    __shared__ int s_n;
+    const int r = RAD > 0 ? RAD : radius, TW = NMS_TW + 2 * r, TH = NMS_TH + 2 * r;
+    float *tile = nms_lds, *hm = nms_lds + TH * TW;
+    const int b = blockIdx.z, x0 = blockIdx.x * NMS_TW, y0 = blockIdx.y * NMS_TH;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float *src = R + (int64_t)b * w * h;
+    const float ninf = -__builtin_inff();
     if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const float *src = R + (int64_t)b * w * h;
-    const float thr = rel_thresh * key_value(maxkey[b]);
-    float v = 0.f;
-    bool ok = x < w && y < h;
-    if (ok) {
-        v = src[(int64_t)y * w + x];
-        ok = v > thr;
-    }
-    if (ok) {
+    // sixteen independent reads in flight per lane (eight rows x two column groups):
+    // one round for radius <= 8
+    for (int yb = ly; yb < TH; yb += 32) {
+        float v[8][2];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int q = 0; q < 8; ++q) {
+            const int yy = yb + 4 * q, gy = y0 - r + yy;
+            const bool row_in = yy < TH && gy >= 0 && gy < h;
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dx == 0 && dy == 0) continue;
-                const int xx = x + dx, yy = y + dy;
-                if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
-                ok = ok && !beaten(src[(int64_t)yy * w + xx], v, dy < 0 || (dy == 0 && dx < 0));
+            for (int c = 0; c < 2; ++c) {
+                const int xx = lx + 64 * c, gx = x0 - r + xx;
+                v[q][c] = (row_in && xx < TW && gx >= 0 && gx < w) ? src[(int64_t)gy * w + gx] : ninf;
             }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int yy = yb + 4 * q;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int xx = lx + 64 * c;
+                if (yy < TH && xx < TW) tile[yy * TW + xx] = v[q][c];
+            }
+        }
     }
-    // block-level compaction: one global atomic per workgroup instead of one per survivor
-    const uint32_t idx = (uint32_t)(y * w + x);
-    int slot = -1;
-    if (ok) slot = atomicAdd(&s_n, 1);
     __syncthreads();
-    if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(&counter[b], s_n);
+    for (int yy = ly; yy < TH; yy += 4) {
+        const float *t = tile + yy * TW + lx;
+        float m = t[0];
+        for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, t[d]);
+        hm[yy * NMS_TW + lx] = m;
+    }
     __syncthreads();
-    if (slot < 0) return;
-    const int pos = s_base + slot;
-    if (final_stage) {
-        if (pos < cap) cand[(int64_t)b * cap + pos] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
-    } else {
-        if (pos < list_cap) list[(int64_t)b * list_cap + pos] = idx;
+    const float thr = rel_thresh * key_value(maxkey[b]);
+    const int py0 = ly * 4;  // this lane finishes tile rows py0..py0+3 of column lx
+    const float *hc = hm + lx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *hj = hc + (py0 + j) * NMS_TW;  // window rows py0+j .. py0+j+2r of the row maxima
+        float above = ninf, rest = ninf;
+        for (int d = 0; d < r; ++d) above = fmaxf(above, hj[d * NMS_TW]);
+        for (int d = r; d <= 2 * r; ++d) rest = fmaxf(rest, hj[d * NMS_TW]);
+        const int gx = x0 + lx, gy = y0 + py0 + j;
+        const float *c = tile + (py0 + j + r) * TW + lx + r;
+        const float v = c[0];
+        bool ok = gx < w && gy < h && v > thr && v >= rest && v > above;
+        if (ok) {
+            float left = ninf;
+            for (int d = 1; d <= r; ++d) left = fmaxf(left, c[-d]);
+            ok = v > left;
+        }
+        if (ok) {
+            const uint32_t idx = (uint32_t)(gy * w + gx);
+            const int slot = atomicAdd(&s_n, 1);
+            const int64_t tile_id = ((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (slot < tile_slots)
+                cand[tile_id * tile_slots + slot] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
+        }
     }
 }
 
-// Stage 2: one wavefront per 3x3 maximum scans its (2r+1)^2 window, 64 neighbours
-// per step; survivors are appended as 64-bit keys.
-__global__ __launch_bounds__(256) void nms_window_kernel(const float *__restrict__ R, int w, int h, int radius,
-                                                         const uint32_t *__restrict__ list, int list_cap,
-                                                         const int *__restrict__ list_count,
-                                                         unsigned long long *__restrict__ cand, int cap,
-                                                         int *__restrict__ counter)
+template <int RAD>
+static void launch_nms_tile(hipStream_t stream, dim3 grid, size_t lds, const float *R, int w, int h, int radius, float rel_thresh,
+                            const uint32_t *maxkey, unsigned long long *cand, int tile_slots)
 {
-    __shared__ unsigned long long s_keys[4][64];   // survivors of one wave, flushed with one atomic
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n = min(list_count[b], list_cap);
-    const int side = 2 * radius + 1, area = side * side;
-    const float *src = R + (int64_t)b * w * h;
-    int kept = 0;
-    for (int c = blockIdx.x * 4 + wv; c < n; c += gridDim.x * 4) {
-        const uint32_t idx = list[(int64_t)b * list_cap + c];
-        const int x = (int)(idx % (uint32_t)w), y = (int)(idx / (uint32_t)w);
-        const float v = src[idx];
-        bool lost = false;
-        for (int k = lane; k < area; k += 64) {
-            const int dy = k / side - radius, dx = k % side - radius;
-            const int xx = x + dx, yy = y + dy;
-            if ((dx | dy) != 0 && xx >= 0 && xx < w && yy >= 0 && yy < h)
-                lost = lost || beaten(src[(int64_t)yy * w + xx], v, dy < 0 || (dy == 0 && dx < 0));
-        }
-        if (__ballot(lost) == 0) {
-            if (lane == 0) s_keys[wv][kept] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
-            ++kept;
-        }
-        if (kept == 64 || c + gridDim.x * 4 >= n) {
-            // flush (wave-uniform): LDS accesses of one wave are ordered
-            int base = 0;
-            if (lane == 0 && kept > 0) base = atomicAdd(&counter[b], kept);
-            base = __shfl(base, 0);
-            if (lane < kept && base + lane < cap) cand[(int64_t)b * cap + base + lane] = s_keys[wv][lane];
-            kept = 0;
-        }
-    }
+    hipLaunchKernelGGL(nms_tile_kernel<RAD>, grid, dim3(256), lds, stream, R, w, h, radius, rel_thresh, maxkey, cand, tile_slots);
 }
 
-__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long long *__restrict__ cand, int cap,
-                                                            const int *__restrict__ counter, int w, int K,
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long long *__restrict__ cand, int cap, int w, int K,
                                                             float *__restrict__ xy, float *__restrict__ scores,
                                                             int *__restrict__ count)
 {
@@ -233,10 +235,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long 
     __shared__ int s_need, s_nsel;
     const int b = blockIdx.x, t = threadIdx.x;
     const unsigned long long *c = cand + (int64_t)b * cap;
-    const int n = min(counter[b], cap);
-    const int m = min(n, K);
-    unsigned long long T = 0;  // K-th largest key (everything >= T is selected)
-    if (n > K) {
+    const int n = cap;  // slots; a zero key is an empty slot
+    if (t == 0) s_nsel = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = t; i < n; i += TOPK_THREADS) mine += c[i] != 0ull;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((t & 63) == 0 && mine) atomicAdd(&s_nsel, mine);
+    __syncthreads();
+    const int valid = s_nsel;
+    __syncthreads();
+    const int m = min(valid, K);
+    unsigned long long T = 1;  // K-th largest key (everything >= T is selected); 1 = every filled slot
+    if (valid > K) {
         if (t == 0) { s_prefix = 0; s_need = K; }
         for (int shift = 56; shift >= 0; shift -= 8) {
             if (t < 256) hist[t] = 0;
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long 
             const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
             for (int i = t; i < n; i += TOPK_THREADS) {
                 const unsigned long long key = c[i];
-                if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+                if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
             }
             __syncthreads();
             if (t == 0) {
@@ -352,8 +363,11 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_nms_topk: bad mem flag %d", mem);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t npix = (size_t)width * height;
-    // two local maxima are more than `radius` apart, so each owns a (radius+1)^2 cell
-    const int cap = ((height + radius) / (radius + 1)) * ((width + radius) / (radius + 1));
+    // survivors are more than `radius` apart, so a 64x16 tile holds at most this many
+    const int tile_slots = ((NMS_TW + radius) / (radius + 1)) * ((NMS_TH + radius) / (radius + 1));
+    dim3 grid((width + NMS_TW - 1) / NMS_TW, (height + NMS_TH - 1) / NMS_TH, batch);
+    VO_REQUIRE(grid.y <= 65535u, "vo_nms_topk: image too tall");
+    const int cap = (int)(grid.x * grid.y) * tile_slots;  // candidate slots per image
     int rc;
     void *p;
     const float *d_R = R;
@@ -368,32 +382,26 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
     }
     if ((rc = vo_stage_reserve(ctx, 5, (size_t)batch * cap * 8, &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
-    // 3x3 maxima are at least 2 apart: at most ceil(h/2)*ceil(w/2) of them
-    const int list_cap = ((height + 1) / 2) * ((width + 1) / 2);
-    uint32_t *d_list = nullptr;
-    if (radius > 1) {
-        if ((rc = vo_stage_reserve(ctx, 7, (size_t)batch * list_cap * 4, &p))) return rc;
-        d_list = (uint32_t *)p;
-    }
-    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * 12, &p))) return rc;
+    VO_HIP_CHECK(hipMemsetAsync(d_cand, 0, (size_t)batch * cap * 8, ctx->stream));
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * 4, &p))) return rc;
     uint32_t *d_max = (uint32_t *)p;
-    int *d_counter = (int *)p + batch;       // final candidates per image
-    int *d_list_count = (int *)p + 2 * batch;  // 3x3 maxima per image
-    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * 12, ctx->stream));
+    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * 4, ctx->stream));
     int mblocks = (int)((npix / 4 + 256 * 4 - 1) / (256 * 4));
     if (mblocks > 512) mblocks = 512;
     if (mblocks < 1) mblocks = 1;
     hipLaunchKernelGGL(max_key_kernel, dim3(mblocks, batch), dim3(256), 0, ctx->stream, d_R, (int64_t)npix, d_max);
-    dim3 grid((width + 63) / 64, (height + 3) / 4, batch);
-    VO_REQUIRE(grid.y <= 65535u, "vo_nms_topk: image too tall");
-    hipLaunchKernelGGL(nms3x3_kernel, grid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh,
-                       (const uint32_t *)d_max, radius == 1 ? 1 : 0, d_cand, cap, d_list, list_cap,
-                       radius == 1 ? d_counter : d_list_count);
-    if (radius > 1)
-        hipLaunchKernelGGL(nms_window_kernel, dim3(512, batch), dim3(256), 0, ctx->stream, d_R, width, height, radius,
-                           (const uint32_t *)d_list, list_cap, (const int *)d_list_count, d_cand, cap, d_counter);
+    const size_t nms_lds = ((size_t)(NMS_TH + 2 * radius) * (NMS_TW + 2 * radius) + (size_t)(NMS_TH + 2 * radius) * NMS_TW) * 4;
+    {
+        typedef void (*launch_fn)(hipStream_t, dim3, size_t, const float *, int, int, int, float, const uint32_t *,
+                                  unsigned long long *, int);
+        static const launch_fn fixed[9] = {launch_nms_tile<0>, launch_nms_tile<1>, launch_nms_tile<2>, launch_nms_tile<3>,
+                                           launch_nms_tile<4>, launch_nms_tile<5>, launch_nms_tile<6>, launch_nms_tile<7>,
+                                           launch_nms_tile<8>};
+        (radius <= 8 ? fixed[radius] : fixed[0])(ctx->stream, grid, nms_lds, d_R, width, height, radius, rel_thresh,
+                                                 (const uint32_t *)d_max, d_cand, tile_slots);
+    }
     hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), 0, ctx->stream, (const unsigned long long *)d_cand, cap,
-                       (const int *)d_counter, width, K, d_xy, d_sc, d_cnt);
+                       width, K, d_xy, d_sc, d_cnt);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_HIP_CHECK(hipMemcpyAsync(xy, d_xy, (size_t)batch * K * 8, hipMemcpyDeviceToHost, ctx->stream));
