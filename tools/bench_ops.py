@@ -86,6 +86,19 @@ def main():
     out.append({"op": "ba_residual", "workload": f"{O} observations", "ms": ms,
                 "reference_numpy_fun_ms_build_container": 16.9})
 
+    # 64 windows in one launch (one per stream of the headline bench): indices offset per window
+    Wn = 64
+    bx = torch.cat([tx[:6 * F].repeat(Wn), tx[6 * F:].repeat(Wn)])
+    bci = torch.cat([tci + w * F for w in range(Wn)])
+    bpi = torch.cat([tpi + w * P for w in range(Wn)])
+    bobs = tobs.repeat(Wn, 1)
+    ms = timed(ctx, lambda: hip.ba_normal_eq(ctx, bx, F * Wn, P * Wn, bci, bpi, bobs, pb["K"], 0))
+    out.append({"op": "ba_normal_eq_batched", "workload": f"{Wn} windows of {F} keyframes x {P} landmarks in one launch, "
+                f"{O * Wn} observations, float64", "ms": ms, "observations_per_s": O * Wn / (ms * 1e-3),
+                "algorithmic_bytes": nbytes * Wn,
+                "roofline": {"bound": "hbm", "achieved": nbytes * Wn / (ms * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
+                             "frac": nbytes * Wn / (ms * 1e-3) / 1e9 / HBM}})
+    del bx, bci, bpi, bobs
     solver = hip.BaSolver(ctx, F, P, tci, tpi, tobs, pb["K"], start)
     solver.linearize(tx)
     for _ in range(3):

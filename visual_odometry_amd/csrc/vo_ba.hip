@@ -122,13 +122,17 @@ __device__ __forceinline__ void ba_obs(const double *cam, const double *X, const
         }
 }
 
-template <bool WITH_J>
+// GATHER: the point Jacobian (2x3) of every observation is stored to Jp_out instead of
+// being summed into Hpp / g with atomics; ba_point_gather_kernel finishes the landmark
+// blocks from landmark-major observation lists.
+template <bool WITH_J, bool GATHER = false>
 __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict__ params, int F, int P,
                                                         const int64_t *__restrict__ ci, const int64_t *__restrict__ pi,
                                                         const double *__restrict__ obs, int O, BaK K, int obs_start,
                                                         double *__restrict__ r, double *__restrict__ cost,
                                                         double *__restrict__ Hcc, double *__restrict__ Hpp,
-                                                        double *__restrict__ Hcp, double *__restrict__ g)
+                                                        double *__restrict__ Hcp, double *__restrict__ g,
+                                                        double *__restrict__ Jp_out = nullptr)
 {
     const int i = blockIdx.x * BA_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -173,8 +177,12 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
 #pragma unroll
             for (int b = 0; b < 3; ++b) hx[a * 3 + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
     }
-    // point blocks: per-lane atomics
-    if (active) {
+    if (GATHER) {
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Jp_out[6 * (int64_t)i + a] = Jp[a];
+        }
+    } else if (active) {  // point blocks: per-lane atomics
         double *hp = Hpp + 9 * p, *gp = g + 6 * (int64_t)F + 3 * p;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -319,7 +327,7 @@ struct vo_ba {
     char *pool = nullptr;
     int64_t *ci = nullptr, *pi = nullptr;
     int *cam32 = nullptr, *pptr = nullptr, *pobs = nullptr, *flag = nullptr;
-    double *obs = nullptr, *r = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
+    double *obs = nullptr, *r = nullptr, *Jp = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
     double *x[2] = {nullptr, nullptr}, *cost[2] = {nullptr, nullptr}, *Hcc[2] = {nullptr, nullptr},
            *Hpp[2] = {nullptr, nullptr}, *Hcp[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};
     int cur = 0;
@@ -527,21 +535,51 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, co
     for (int a = 0; a < 3; ++a) x_new[at + a] = x[at + a] + d[a];
 }
 
+// Hpp[p] = sum Jp^T Jp, g_p = sum Jp^T r over the observations of landmark p (one lane per
+// landmark; observations without Jacobian rows carry Jp = 0).
+__global__ __launch_bounds__(256) void ba_point_gather_kernel(int P, int F, const int *__restrict__ pptr,
+                                                              const int *__restrict__ pobs, const double *__restrict__ Jp,
+                                                              const double *__restrict__ r, double *__restrict__ Hpp,
+                                                              double *__restrict__ g)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+    for (int o = pptr[p]; o < pptr[p + 1]; ++o) {
+        const int64_t i = pobs[o];
+        const double *j = Jp + 6 * i;
+        const double j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3], j4 = j[4], j5 = j[5];
+        const double r0 = r[2 * i], r1 = r[2 * i + 1];
+        h[0] += j0 * j0 + j3 * j3; h[1] += j0 * j1 + j3 * j4; h[2] += j0 * j2 + j3 * j5;
+        h[3] += j1 * j1 + j4 * j4; h[4] += j1 * j2 + j4 * j5; h[5] += j2 * j2 + j5 * j5;
+        gp[0] += j0 * r0 + j3 * r1; gp[1] += j1 * r0 + j4 * r1; gp[2] += j2 * r0 + j5 * r1;
+    }
+    double *hp = Hpp + 9 * (int64_t)p;
+    hp[0] = h[0]; hp[1] = h[1]; hp[2] = h[2];
+    hp[3] = h[1]; hp[4] = h[3]; hp[5] = h[4];
+    hp[6] = h[2]; hp[7] = h[4]; hp[8] = h[5];
+    double *gq = g + 6 * (int64_t)F + 3 * (int64_t)p;
+    gq[0] = gp[0]; gq[1] = gp[1]; gq[2] = gp[2];
+}
+
 static int ba_linearize_into(vo_ba *ba, int slot)
 {
     vo_ctx *ctx = ba->ctx;
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
     VO_HIP_CHECK(hipMemsetAsync(ba->cost[slot], 0, 8, ctx->stream));
+    (void)np_;
     if (ba->F) VO_HIP_CHECK(hipMemsetAsync(ba->Hcc[slot], 0, (size_t)ba->F * 288, ctx->stream));
-    if (ba->P) VO_HIP_CHECK(hipMemsetAsync(ba->Hpp[slot], 0, (size_t)ba->P * 72, ctx->stream));
-    if (np_) VO_HIP_CHECK(hipMemsetAsync(ba->g[slot], 0, np_ * 8, ctx->stream));
+    if (ba->n) VO_HIP_CHECK(hipMemsetAsync(ba->g[slot], 0, (size_t)ba->n * 8, ctx->stream));  // camera part; the gather writes the rest
     if (ba->O) {
         const unsigned blocks = (unsigned)((ba->O + BA_THREADS - 1) / BA_THREADS);
-        hipLaunchKernelGGL(ba_kernel<true>, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P, ba->ci,
-                           ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot], ba->Hpp[slot],
-                           ba->Hcp[slot], ba->g[slot]);
+        hipLaunchKernelGGL((ba_kernel<true, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P,
+                           ba->ci, ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot],
+                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->Jp);
         VO_HIP_CHECK(hipGetLastError());
     }
+    hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
+                       ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot]);
+    VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
 
@@ -611,7 +649,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         size_t tot = 0;
         auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
         const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
-                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16),
+                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48),
                      o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8);
         size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
         for (int s = 0; s < 2; ++s) {
@@ -626,7 +664,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             char *b = ba->pool;
             ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
             ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
-            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Dpinv = (double *)(b + o_dpi);
+            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->Dpinv = (double *)(b + o_dpi);
             ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
             for (int s = 0; s < 2; ++s) {
                 ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
