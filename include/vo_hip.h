@@ -212,6 +212,25 @@ int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int 
 int vo_ba_accept(vo_ctx *ctx, vo_ba *ba);
 int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, int mem);
 
+/* ---- RANSAC bookkeeping and refit ----------------------------------------------------
+ * vo_ransac_draw_subsets (host-side, no GPU work): the sample drawing of OpenCV's
+ * RANSAC loop behind cv2.findFundamentalMat (vo_pipeline/bootstrap.py:246-252) and
+ * cv.solvePnPRansac (vo_pipeline/poseEstimation.py:61-69): cv::RNG multiply-with-carry
+ * generator (*rng_state in/out, OpenCV starts from 2^64-1), distinct indices per subset;
+ * with m1/m2 ((count,2) float32, host) subsets whose last point is collinear with an earlier
+ * pair in either set are redrawn (up to max_attempts).  subsets: (n_subsets, model_points) int32.
+ *
+ * vo_refine_pose: Gauss-Newton refit of one pose on the correspondences selected by
+ * mask (NULL = all), the step cv.solvePnPRansac performs on the inliers after its loop.
+ * X (n,3) float32, x (n,2) float32, mask (n) uint8 follow `mem`; K (3,3), pose_in and
+ * pose_out (rotation vector, translation: 6 float64) and cost_out are host pointers.
+ * Synchronises the stream.
+ */
+int vo_ransac_draw_subsets(uint64_t *rng_state, int count, int model_points, int n_subsets, const float *m1,
+                           const float *m2, int max_attempts, int32_t *subsets);
+int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n, const uint8_t *mask, const double *K,
+                   const double *pose_in, int max_iters, double *pose_out, double *cost_out, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,60 @@ def test_ransac_iteration_rule_and_replay():
     assert all(len(set(r)) == 7 for r in s1) and s1.min() >= 0 and s1.max() < 50
 
 
+def _collinear_with_last(pts):
+    """haveCollinearPoints of OpenCV: float32 differences, float64 products."""
+    i = pts.shape[0] - 1
+    d = (pts[:i] - pts[i]).astype(np.float64)
+    for j in range(i):
+        for k in range(j):
+            if abs(d[k, 0] * d[j, 1] - d[k, 1] * d[j, 0]) <= 1.1920929e-07 * (abs(d[j, 0]) + abs(d[j, 1]) + abs(d[k, 0]) + abs(d[k, 1])):
+                return True
+    return False
+
+
+def _draw_subsets_py(rng, count, model_points, n_subsets, m1=None, m2=None, max_attempts=10000):
+    """Pure-Python statement of the sampling rule (generator, distinct indices, collinearity re-draw)."""
+    out = np.empty((n_subsets, model_points), np.int64)
+    for s in range(n_subsets):
+        for _ in range(max_attempts):
+            idx = []
+            while len(idx) < model_points:
+                j = rng.uniform(0, count)
+                if j not in idx:
+                    idx.append(j)
+            if m1 is not None and (_collinear_with_last(m1[idx]) or _collinear_with_last(m2[idx])):
+                continue
+            break
+        out[s] = idx
+    return out
+
+
+def test_subset_sampler_matches_python_statement():
+    # known first outputs of cv::RNG(2^64-1): state -> (uint32)state * 4164903690 + (state >> 32)
+    r = ransac.CvRNG()
+    st = 0xFFFFFFFFFFFFFFFF
+    for _ in range(3):
+        st = ((st & 0xFFFFFFFF) * 4164903690 + (st >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert r.next() == st & 0xFFFFFFFF
+    for count, mp, n in ((50, 7, 40), (9, 4, 25), (4, 4, 3), (1000, 7, 100)):
+        a, b = ransac.CvRNG(), ransac.CvRNG()
+        got = ransac.draw_subsets(a, count, mp, n)
+        want = _draw_subsets_py(b, count, mp, n)
+        np.testing.assert_array_equal(got, want)
+        assert a.state == b.state and got.dtype == np.int32
+    # grid points: many collinear triples, so the re-draw path is exercised; second call continues the stream
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5)), -1).reshape(-1, 2).astype(np.float32) * 7.5
+    g2 = g[::-1].copy() + np.float32(0.25)
+    a, b = ransac.CvRNG(), ransac.CvRNG()
+    for _ in range(2):
+        np.testing.assert_array_equal(ransac.draw_subsets(a, 30, 7, 30, g, g2, 50), _draw_subsets_py(b, 30, 7, 30, g, g2, 50))
+        assert a.state == b.state
+    plain = ransac.draw_subsets(ransac.CvRNG(), 30, 7, 30)
+    assert not np.array_equal(plain, ransac.draw_subsets(ransac.CvRNG(), 30, 7, 30, g, g2, 50))
+    with pytest.raises(ValueError):
+        ransac.draw_subsets(ransac.CvRNG(), 3, 4, 1)
+
+
 def test_numpy_solvers_on_planted_geometry():
     """The independent numpy solvers (checkers of the GPU solvers) recover planted geometry."""
     from oracle import solvers_np

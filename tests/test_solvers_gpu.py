@@ -104,3 +104,59 @@ def test_solver_device_buffers_and_degenerate(ctx):
     assert (valid == 0).all() and (Rt == 0).all()
     Rt, valid = hip.p3p_solve(ctx, sc["X"], sc["m2"], sc["K"], np.zeros((0, 4), np.int32))
     assert Rt.shape == (0, 3, 4)
+
+
+def test_refine_pose_one_launch(oracle, ctx):
+    """vo_refine_pose against a numpy Gauss-Newton on the oracle's normal equations, with and without a mask."""
+    from scipy.spatial.transform import Rotation
+    from visual_odometry_amd import hip
+    sc = synth.two_view_scene(n=400, K=synth.K_KITTI, shape=synth.KITTI_SHAPE, noise=0.2, inlier_frac=0.8, seed=12)
+    X, x, K = sc["X"], sc["m2"], sc["K"]
+    inl = sc["inliers"].astype(np.uint8) if "inliers" in sc else None
+    if inl is None:
+        proj = (sc["X"].astype(np.float64) @ sc["R"].T + sc["t"]) @ K.T
+        inl = (np.linalg.norm(proj[:, :2] / proj[:, 2:] - x, axis=1) < 2.0).astype(np.uint8)
+    assert 100 < inl.sum() < 400
+    rv0 = Rotation.from_matrix(sc["R"]).as_rotvec() + [0.01, -0.02, 0.015]
+    t0 = sc["t"] + [0.05, -0.03, 0.04]
+
+    def numpy_gn(Xs, xs, iters):
+        cam = np.hstack([rv0, t0])
+        n = Xs.shape[0]
+        ci, pi = np.zeros(n, np.int64), np.arange(n, dtype=np.int64)
+        prev, prev_cam, last = np.inf, cam.copy(), np.inf
+        for it in range(iters + 1):
+            ne = oracle.ba_normal_eq(np.hstack([cam, Xs.astype(np.float64).ravel()]), 1, n, ci, pi, xs.astype(np.float64), K, 0)
+            c = float(ne["cost"])
+            if not np.isfinite(c) or c > prev * (1 + 1e-12):
+                return prev_cam, last
+            last = c
+            if it == iters or (prev < np.inf and prev - c < 1e-10 * max(c, 1e-300)):
+                return cam, last
+            H, g = ne["Hcc"][0], ne["g"][:6]
+            step = np.linalg.solve(H + 1e-9 * np.trace(H) / 6 * np.eye(6), -g)
+            prev, prev_cam = c, cam.copy()
+            cam = cam + step
+        return cam, last
+
+    sel = inl.astype(bool)
+    want, wcost = numpy_gn(X[sel], x[sel], 10)
+    rv, t, cost = hip.refine_pose(ctx, X, x, K, rv0, t0, mask=inl, max_iters=10)
+    np.testing.assert_allclose(np.hstack([rv, t]), want, rtol=0, atol=1e-8)
+    assert cost == pytest.approx(wcost, rel=1e-9)
+    np.testing.assert_allclose(Rotation.from_rotvec(rv).as_matrix(), sc["R"], atol=2e-3)
+    # no mask = every correspondence (outliers pull the pose; only parity with the numpy loop is checked)
+    want_all, _ = numpy_gn(X, x, 3)
+    rv, t, _ = hip.refine_pose(ctx, X, x, K, rv0, t0, max_iters=3)
+    np.testing.assert_allclose(np.hstack([rv, t]), want_all, rtol=1e-7, atol=1e-7)
+    # device-resident inputs, zero iterations = cost of the start pose
+    import torch
+    rv, t, c0 = hip.refine_pose(ctx, torch.from_numpy(X).cuda(), torch.from_numpy(x).cuda(), K, rv0, t0,
+                                mask=torch.from_numpy(inl).cuda(), max_iters=0)
+    np.testing.assert_array_equal(np.hstack([rv, t]), np.hstack([rv0, t0]))
+    ref0 = float(oracle.ba_residual(np.hstack([rv0, t0, X[sel].astype(np.float64).ravel()]), 1, int(sel.sum()),
+                                    np.zeros(int(sel.sum()), np.int64), np.arange(int(sel.sum()), dtype=np.int64),
+                                    x[sel].astype(np.float64), K)[1])
+    assert c0 == pytest.approx(ref0, rel=1e-9)
+    with pytest.raises(ValueError):
+        hip.refine_pose(ctx, X, x[:-1], K, rv0, t0)

@@ -32,12 +32,31 @@ def main():
     sc = synth.two_view_scene(n=2000, K=synth.K_KITTI, shape=synth.KITTI_SHAPE, seed=3)
     pe = PoseEstimation(synth.K_KITTI, algo_method_type=AlgoMethod.P3P)
     tp = TrackPoints(21, 10, 0.1)
+    from scipy.spatial.transform import Rotation
+    from visual_odometry_amd.vo_pipeline.bundleAdjustment import BundleAdjustment
+    pb = synth.ba_problem(F=10, P=2000, visibility=0.8, seed=1, obs_noise=0.3)
+    rng = np.random.default_rng(0)
+    cams = pb["x"][:60].reshape(10, 6).copy()
+    cams[3:, 3:] += rng.normal(0, 0.02, (7, 3))
+    M = np.zeros((10, 3, 4), np.float32)
+    for i in range(10):
+        M[i, :, :3] = Rotation.from_rotvec(cams[i, :3]).as_matrix()
+        M[i, :, 3] = cams[i, 3:]
+    landmarks = (pb["x"][60:].reshape(-1, 3) + rng.normal(0, 0.1, (2000, 3))).astype(np.float32)
+    ba = BundleAdjustment(synth.K_KITTI)
+    p1 = np.hstack([sc["m1"], np.ones((2000, 1), np.float32)]).astype(np.float32)
+    p2 = np.hstack([sc["m2"], np.ones((2000, 1), np.float32)]).astype(np.float32)
+    M1 = (synth.K_KITTI @ np.eye(3, 4)).astype(np.float32)
+    M2 = synth.K_KITTI.astype(np.float64) @ np.hstack([sc["R"], sc["t"].reshape(3, 1)])
     res = {
         "PoseEstimation.KLT ms (1241x376, 2000 kp, host arrays, both pyramids rebuilt)": t(lambda: PoseEstimation.KLT(img0, img1, pts)),
         "TrackPoints.trackKLT ms (forward+backward)": t(lambda: tp.trackKLT(img0, img1, pts)),
         "PoseEstimation.PnP ms (2000 points, 100 RANSAC iterations + refit)": t(lambda: pe.PnP(sc["X"], sc["m2"]), reps=10),
         "findFundamentalMat ms (2000 points, 100 iterations)": t(lambda: BootstrapInitializer.findFundamentalMat(sc["m1"], sc["m2"], 0.1, 0.9999, 100), reps=10),
         "FeatureExtractor.corners ms (top-2000)": t(lambda: FeatureExtractor.corners(img0, 2000)),
+        "BootstrapInitializer._linear_triangulation ms (2000 pairs)": t(lambda: BootstrapInitializer._linear_triangulation(p1, p2, M1, M2)),
+        f"BundleAdjustment.bundle_adjustment ms (10 keyframes x 2000 landmarks, {pb['ci'].size} observations, to ftol 1e-4)":
+            t(lambda: ba.bundle_adjustment(M, landmarks, pb["ci"], pb["pi"], pb["obs"]), reps=5, warm=1),
     }
     print(json.dumps(res, indent=1))
 

@@ -67,6 +67,10 @@ SIGNATURES = {
     "vo_ba_try_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_f64p, ctypes.POINTER(ctypes.c_int)]),
     "vo_ba_accept": (ctypes.c_int, [c_vp, c_vp]),
     "vo_ba_params": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int]),
+    "vo_ransac_draw_subsets": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                              c_vp, ctypes.c_int, c_vp]),
+    "vo_refine_pose": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p,
+                                      ctypes.c_int]),
 }
 
 _lib = None

@@ -308,6 +308,164 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 }
 
 // ---------------------------------------------------------------------------
+// Pose-only Gauss-Newton refinement in one launch: the refit on the inliers that
+// follows the RANSAC loop inside cv.solvePnPRansac (vo_pipeline/poseEstimation.py:61-69;
+// OpenCV refits with its own PnP solver, this minimises the same reprojection error).
+// One workgroup: every iteration sums the 6x6 normal equations over the selected
+// correspondences (DPP wave sums, then across waves in LDS), lane 0 solves the damped
+// system by Cholesky.  Stops when the cost rises (the previous pose is returned), stops
+// improving by more than 1e-10 relative, or after max_iters.
+// ---------------------------------------------------------------------------
+#define REFINE_THREADS 1024
+struct Pose6 { double v[6]; };
+
+__global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float *__restrict__ X, const float *__restrict__ x,
+                                                                     const uint8_t *__restrict__ mask, int n, BaK K, Pose6 start,
+                                                                     int max_iters, double *__restrict__ out)
+{
+    __shared__ double red[REFINE_THREADS / 64][28];
+    __shared__ double tot[28];
+    __shared__ double cam_s[6];
+    __shared__ int stop_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double cam[6], prev_cam[6], prev_cost = __builtin_inf(), last_cost = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { cam[k] = start.v[k]; prev_cam[k] = start.v[k]; }
+    int iters_done = 0;
+    for (int it = 0; it <= max_iters; ++it) {
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = 0;
+        for (int i = tid; i < n; i += REFINE_THREADS) {
+            if (mask && !mask[i]) continue;
+            const double Xd[3] = {(double)X[3 * (int64_t)i], (double)X[3 * (int64_t)i + 1], (double)X[3 * (int64_t)i + 2]};
+            const double ob[2] = {(double)x[2 * (int64_t)i], (double)x[2 * (int64_t)i + 1]};
+            double rr[2], Jc[12], Jp[6];
+            ba_obs<true>(cam, Xd, K, ob, rr, Jc, Jp);
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[e++] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += Jc[a] * rr[0] + Jc[6 + a] * rr[1];
+            acc[27] += 0.5 * (rr[0] * rr[0] + rr[1] * rr[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 28; ++k) {
+            const double s = wave_sum_d(acc[k]);
+            if (lane == 63) red[wv][k] = s;
+        }
+        __syncthreads();
+        if (tid < 28) {
+            double s = 0;
+            for (int w = 0; w < REFINE_THREADS / 64; ++w) s += red[w][tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double cost = tot[27];
+            int stop = 0;
+            if (!(cost == cost) || fabs(cost) == __builtin_inf() || cost > prev_cost * (1 + 1e-12)) {
+                // diverged: fall back to the pose before the last step
+                for (int k = 0; k < 6; ++k) cam[k] = prev_cam[k];
+                stop = 1;
+            } else {
+                last_cost = cost;
+                if (it == max_iters || (prev_cost < __builtin_inf() && prev_cost - cost < 1e-10 * fmax(cost, 1e-300))) stop = 1;
+            }
+            if (!stop) {
+                double A[6][6], g[6];
+                int e = 0;
+                double tr = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = a; b < 6; ++b) { A[a][b] = tot[e]; A[b][a] = tot[e]; ++e; }
+                for (int a = 0; a < 6; ++a) { tr += A[a][a]; g[a] = -tot[21 + a]; }
+                for (int a = 0; a < 6; ++a) A[a][a] += 1e-9 * tr / 6;
+                bool ok = true;
+                for (int k = 0; k < 6 && ok; ++k) {       // Cholesky, lower triangle in place
+                    double d = A[k][k];
+                    for (int m = 0; m < k; ++m) d -= A[k][m] * A[k][m];
+                    if (!(d > 0)) { ok = false; break; }
+                    A[k][k] = sqrt(d);
+                    for (int i = k + 1; i < 6; ++i) {
+                        double v = A[i][k];
+                        for (int m = 0; m < k; ++m) v -= A[i][m] * A[k][m];
+                        A[i][k] = v / A[k][k];
+                    }
+                }
+                if (!ok) stop = 1;
+                else {
+                    for (int k = 0; k < 6; ++k) {
+                        double v = g[k];
+                        for (int m = 0; m < k; ++m) v -= A[k][m] * g[m];
+                        g[k] = v / A[k][k];
+                    }
+                    for (int k = 5; k >= 0; --k) {
+                        double v = g[k];
+                        for (int m = k + 1; m < 6; ++m) v -= A[m][k] * g[m];
+                        g[k] = v / A[k][k];
+                    }
+                    prev_cost = cost;
+                    for (int k = 0; k < 6; ++k) { prev_cam[k] = cam[k]; cam[k] += g[k]; }
+                    iters_done = it + 1;
+                }
+            }
+            for (int k = 0; k < 6; ++k) cam_s[k] = cam[k];
+            stop_s = stop;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cam[k] = cam_s[k];
+        if (stop_s) break;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int k = 0; k < 6; ++k) out[k] = cam[k];
+        out[6] = last_cost;
+        out[7] = (double)iters_done;
+    }
+}
+
+extern "C" int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n, const uint8_t *mask, const double *K,
+                              const double *pose_in, int max_iters, double *pose_out, double *cost_out, int mem)
+{
+    VO_REQUIRE(ctx && K && pose_in && pose_out, "vo_refine_pose: NULL argument");
+    VO_REQUIRE(n >= 0 && max_iters >= 0, "vo_refine_pose: n=%d max_iters=%d", n, max_iters);
+    VO_REQUIRE(n == 0 || (X && x), "vo_refine_pose: NULL point buffers");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_refine_pose: bad mem flag %d", mem);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    BaK Kv;
+    memcpy(Kv.k, K, sizeof(Kv.k));
+    Pose6 start;
+    memcpy(start.v, pose_in, sizeof(start.v));
+    const float *dX = X, *dx = x;
+    const uint8_t *dm = mask;
+    int rc;
+    void *p;
+    if (mem == VO_MEM_HOST && n) {
+        if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 12, &p))) return rc; dX = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc; dx = (const float *)p;
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (mask) {
+            if ((rc = vo_stage_reserve(ctx, 2, (size_t)n, &p))) return rc; dm = (const uint8_t *)p;
+            VO_HIP_CHECK(hipMemcpyAsync((void *)dm, mask, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
+    double *d_out = (double *)p;
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dm, n, Kv, start, max_iters, d_out);
+    VO_HIP_CHECK(hipGetLastError());
+    double h[8];
+    VO_HIP_CHECK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(pose_out, h, 6 * sizeof(double));
+    if (cost_out) *cost_out = h[6];
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Device-resident Levenberg-Marquardt state for one bundle-adjustment window.
 //
 // The reference solves the window with scipy's least_squares (trf + lsmr,

@@ -509,3 +509,49 @@ class BaSolver:
             self.close()
         except Exception:
             pass
+
+
+def ransac_draw_subsets(rng_state: int, count: int, model_points: int, n_subsets: int, m1=None, m2=None,
+                        max_attempts: int = 10000) -> Tuple[np.ndarray, int]:
+    """Host-side: n_subsets index sets drawn as OpenCV's RANSAC loop draws them -> (subsets (n_subsets, model_points)
+    int32, new generator state).  m1/m2 (count,2) float32 enable the collinearity re-draw of the F estimator."""
+    lib = _lib.load()
+    st = ctypes.c_uint64(rng_state & 0xFFFFFFFFFFFFFFFF)
+    out = np.empty((int(n_subsets), int(model_points)), np.int32)
+    if m1 is not None:
+        m1 = np.ascontiguousarray(m1, np.float32).reshape(-1, 2)
+        m2 = np.ascontiguousarray(m2, np.float32).reshape(-1, 2)
+        if m1.shape[0] != count or m2.shape[0] != count:
+            raise ValueError("ransac_draw_subsets: point sets must have `count` rows")
+    check(lib.vo_ransac_draw_subsets(ctypes.byref(st), int(count), int(model_points), int(n_subsets),
+                                     _ptr(m1) if m1 is not None else None, _ptr(m2) if m2 is not None else None,
+                                     int(max_attempts), _ptr(out)), "vo_ransac_draw_subsets")
+    return out, int(st.value)
+
+
+def refine_pose(ctx: Context, X, x, K, rvec, t, mask=None, max_iters: int = 10):
+    """Gauss-Newton refit of one pose (rotation vector, translation) on the correspondences selected by mask
+    (None = all), one launch -> (rvec (3,), t (3,), cost)."""
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    start = np.ascontiguousarray(np.hstack([np.asarray(rvec, np.float64).ravel(), np.asarray(t, np.float64).ravel()]))
+    if start.size != 6:
+        raise ValueError("refine_pose: rvec and t must have 3 entries each")
+    if _is_torch(X):
+        X, x = X.contiguous(), x.contiguous()
+        if mask is not None:
+            mask = mask.contiguous()
+        mem, n = VO_MEM_DEVICE, int(X.shape[0])
+    else:
+        X = np.ascontiguousarray(X, np.float32).reshape(-1, 3)
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8).ravel()
+        mem, n = VO_MEM_HOST, int(X.shape[0])
+    if int(x.shape[0]) != n or (mask is not None and int(mask.shape[0]) != n):
+        raise ValueError("refine_pose: X, x and mask differ in length")
+    out = np.empty(6, np.float64)
+    cost = ctypes.c_double()
+    check(ctx.lib.vo_refine_pose(ctx.handle, _ptr(X), _ptr(x), n, _ptr(mask) if mask is not None else None,
+                                 Kd.ctypes.data_as(_lib.c_f64p), start.ctypes.data_as(_lib.c_f64p), int(max_iters),
+                                 out.ctypes.data_as(_lib.c_f64p), ctypes.byref(cost), mem), "vo_refine_pose")
+    return out[:3].copy(), out[3:].copy(), cost.value

@@ -49,33 +49,12 @@ def ransac_update_num_iters(p: float, ep: float, model_points: int, max_iters: i
     return max_iters if (denom >= 0 or -num >= max_iters * (-denom)) else int(round(num / denom))
 
 
-def _collinear_with_last(pts: np.ndarray) -> bool:
-    """OpenCV's haveCollinearPoints: is the last point (nearly) on a line through two earlier ones."""
-    i = pts.shape[0] - 1
-    d1 = pts[:i] - pts[i]
-    for j in range(i):
-        for k in range(j):
-            if abs(d1[k, 0] * d1[j, 1] - d1[k, 1] * d1[j, 0]) <= 1.1920929e-07 * (abs(d1[j, 0]) + abs(d1[j, 1]) + abs(d1[k, 0]) + abs(d1[k, 1])):
-                return True
-    return False
-
-
 def draw_subsets(rng: CvRNG, count: int, model_points: int, n_subsets: int, m1: Optional[np.ndarray] = None,
                  m2: Optional[np.ndarray] = None, max_attempts: int = 10000) -> np.ndarray:
     """n_subsets index sets of distinct indices drawn as RANSACPointSetRegistrator::getSubset does;
-    with m1/m2 given, subsets whose last point is collinear with an earlier pair are redrawn."""
-    out = np.empty((n_subsets, model_points), np.int64)
-    for s in range(n_subsets):
-        for _ in range(max_attempts):
-            idx = []
-            while len(idx) < model_points:
-                j = rng.uniform(0, count)
-                if j not in idx:
-                    idx.append(j)
-            if m1 is not None and (_collinear_with_last(m1[idx]) or _collinear_with_last(m2[idx])):
-                continue
-            break
-        out[s] = idx
+    with m1/m2 given, subsets whose last point is collinear with an earlier pair are redrawn
+    (host-side routine of the library; advances rng)."""
+    out, rng.state = hip.ransac_draw_subsets(rng.state, count, model_points, n_subsets, m1, m2, max_attempts)
     return out
 
 
@@ -128,31 +107,13 @@ def find_fundamental_mat(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: f
 
 
 # ---------------------------------------------------------------- PnP by RANSAC
-def refine_pose(ctx, X: np.ndarray, x: np.ndarray, K: np.ndarray, R: np.ndarray, t: np.ndarray, iters: int = 10):
-    """Gauss-Newton on the reprojection error over the given correspondences (pose only); the
-    6x6 normal equations come from the GPU BA kernel with the points held fixed."""
+def refine_pose(ctx, X: np.ndarray, x: np.ndarray, K: np.ndarray, R: np.ndarray, t: np.ndarray, iters: int = 10,
+                mask: Optional[np.ndarray] = None):
+    """Gauss-Newton on the reprojection error over the correspondences selected by mask (pose only), one
+    GPU launch (vo_refine_pose) -> (R (3,3), t (3,))."""
     from scipy.spatial.transform import Rotation
-    n = X.shape[0]
-    cam = np.hstack([Rotation.from_matrix(R).as_rotvec(), t]).astype(np.float64)
-    ci = np.zeros(n, np.int64)
-    pi = np.arange(n, dtype=np.int64)
-    obs = x.astype(np.float64)
-    pts = X.astype(np.float64).ravel()
-    prev = np.inf
-    for _ in range(iters):
-        ne = hip.ba_normal_eq(ctx, np.hstack([cam, pts]), 1, n, ci, pi, obs, K, 0)
-        if not np.isfinite(ne["cost"]) or ne["cost"] > prev * (1 + 1e-12):
-            break
-        H, g = ne["Hcc"][0], ne["g"][:6]
-        try:
-            step = np.linalg.solve(H + 1e-9 * np.trace(H) / 6 * np.eye(6), -g)
-        except np.linalg.LinAlgError:
-            break
-        if prev - ne["cost"] < 1e-10 * max(ne["cost"], 1e-300) and prev < np.inf:
-            break
-        prev = ne["cost"]
-        cam = cam + step
-    return Rotation.from_rotvec(cam[:3]).as_matrix(), cam[3:].copy()
+    rvec, t2, _ = hip.refine_pose(ctx, X, x, K, Rotation.from_matrix(R).as_rotvec(), t, mask, iters)
+    return Rotation.from_rotvec(rvec).as_matrix(), t2
 
 
 def solve_pnp_ransac(X: np.ndarray, x: np.ndarray, K: np.ndarray, thr: float, conf: float, max_iters: int,
@@ -184,7 +145,7 @@ def solve_pnp_ransac(X: np.ndarray, x: np.ndarray, K: np.ndarray, thr: float, co
     inl = np.nonzero(mask[0])[0]
     R, t = Rt[win][:, :3], Rt[win][:, 3]
     if inl.size >= 4:
-        R2, t2 = refine_pose(ctx, X[inl], x[inl], Kd, R, t)
+        R2, t2 = refine_pose(ctx, X, x, Kd, R, t, mask=mask[0])
         if np.all(np.isfinite(R2)) and np.all(np.isfinite(t2)):
             R, t = R2, t2
     return True, R, t, inl.astype(np.int32).reshape(-1, 1)
