@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #define BA_THREADS 256
+#define BA_REPLICAS 16  // copies of the camera blocks that the per-wave atomics are spread over
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_d(double v)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
                                                         double *__restrict__ r, double *__restrict__ cost,
                                                         double *__restrict__ Hcc, double *__restrict__ Hpp,
                                                         double *__restrict__ Hcp, double *__restrict__ g,
-                                                        double *__restrict__ Jp_out = nullptr)
+                                                        double *__restrict__ cam_rep, double *__restrict__ Jp_out = nullptr)
 {
     const int i = blockIdx.x * BA_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -191,34 +192,79 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
             unsafeAtomicAdd(gp + a, Jp[a] * rr[0] + Jp[3 + a] * rr[1]);
         }
     }
-    // camera blocks: when every active lane of the wave sees one camera, reduce
-    // over the wave first (the caller's observations are sorted by camera)
+    // camera blocks: when every active lane of the wave sees one camera, reduce over the
+    // wave first (the caller's observations are sorted by camera).  The sums go to one of
+    // BA_REPLICAS copies of the camera blocks chosen by workgroup, so that the float64
+    // atomics of the many waves of one camera do not queue on the same few cache lines;
+    // ba_cam_sum_kernel adds the copies up.
     const unsigned long long act = __ballot(active);
     if (act == 0) return;
+    double *rep = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42;
     const int first = __ffsll((long long)act) - 1;
     const long long c0 = __shfl((long long)c, first);
     const bool uniform_cam = __ballot(active && c != c0) == 0;
     if (uniform_cam) {
-        double *hc = Hcc + 36 * c0, *gc = g + 6 * c0;
+        // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r: every lane parks its 27 terms in
+        // LDS (row per term, column per lane), 54 lanes each add up half a row, one shuffle joins
+        // the halves, and 27 lanes issue the atomics (mirroring the off-diagonal entries).
+        if constexpr (WITH_J) {
+            __shared__ double red[BA_THREADS / 64][27][65];
+            double(*mine)[65] = red[threadIdx.x >> 6];
+            int e = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+            for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                double s = wave_sum_d(Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-                if (lane == 63) unsafeAtomicAdd(hc + a * 6 + b, s);
+                for (int b = a; b < 6; ++b) mine[e++][lane] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) mine[21 + a][lane] = Jc[a] * rr[0] + Jc[6 + a] * rr[1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int v = lane % 27, half = lane / 27;   // lanes 54..63 repeat rows 0..9 (third "half" is ignored)
+            const double *row = &mine[v][(half & 1) * 32];
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) { s0 += row[i]; s1 += row[i + 1]; s2 += row[i + 2]; s3 += row[i + 3]; }
+            const double part = (s0 + s1) + (s2 + s3);
+            const double other = __shfl_down(part, 27);
+            if (lane < 27) {
+                const double tot = part + other;
+                double *hc = rep + 42 * c0;
+                // term index -> (a, b) of the upper triangle, row-major
+                const int ta = lane < 6 ? 0 : lane < 11 ? 1 : lane < 15 ? 2 : lane < 18 ? 3 : lane < 20 ? 4 : 5;
+                const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
+                if (lane < 21) {
+                    const int tb = ta + (lane - first_of_row);
+                    unsafeAtomicAdd(hc + ta * 6 + tb, tot);
+                    if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, tot);
+                } else {
+                    unsafeAtomicAdd(hc + 36 + (lane - 21), tot);
+                }
             }
-            double s = wave_sum_d(Jc[a] * rr[0] + Jc[6 + a] * rr[1]);
-            if (lane == 63) unsafeAtomicAdd(gc + a, s);
         }
     } else if (active) {
-        double *hc = Hcc + 36 * c, *gc = g + 6 * c;
+        double *hc = rep + 42 * c;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
             for (int b = 0; b < 6; ++b) unsafeAtomicAdd(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-            unsafeAtomicAdd(gc + a, Jc[a] * rr[0] + Jc[6 + a] * rr[1]);
+            unsafeAtomicAdd(hc + 36 + a, Jc[a] * rr[0] + Jc[6 + a] * rr[1]);
         }
     }
+}
+
+// Hcc[c] and g[6c..6c+5] = sum over the replicas filled by ba_kernel (overwrites both).
+__global__ __launch_bounds__(256) void ba_cam_sum_kernel(int F, const double *__restrict__ cam_rep, double *__restrict__ Hcc,
+                                                         double *__restrict__ g)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= F * 42) return;
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < BA_REPLICAS; ++r) s += cam_rep[(size_t)r * F * 42 + t];
+    const int c = t / 42, e = t - 42 * c;
+    if (e < 36) Hcc[36 * (int64_t)c + e] = s;
+    else g[6 * (int64_t)c + (e - 36)] = s;
 }
 
 template <bool WITH_J>
@@ -267,15 +313,24 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
         }
     }
     VO_HIP_CHECK(hipMemsetAsync(d_cost, 0, 8, ctx->stream));
+    double *d_rep = nullptr;
     if (WITH_J) {
-        if (F) VO_HIP_CHECK(hipMemsetAsync(d_Hcc, 0, (size_t)F * 288, ctx->stream));
+        void *rp;
+        const size_t rep_bytes = (size_t)BA_REPLICAS * (F ? F : 1) * 42 * 8;
+        if ((rc = vo_stage_reserve(ctx, 1, rep_bytes, &rp))) return rc;
+        d_rep = (double *)rp;
+        VO_HIP_CHECK(hipMemsetAsync(d_rep, 0, rep_bytes, ctx->stream));
         if (P) VO_HIP_CHECK(hipMemsetAsync(d_Hpp, 0, (size_t)P * 72, ctx->stream));
-        if (np_) VO_HIP_CHECK(hipMemsetAsync(d_g, 0, np_ * 8, ctx->stream));
+        if (P) VO_HIP_CHECK(hipMemsetAsync(d_g + 6 * (size_t)F, 0, (size_t)P * 24, ctx->stream));
     }
     if (O) {
         const unsigned blocks = (unsigned)((O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL(ba_kernel<WITH_J>, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, d_params, F, P, d_ci, d_pi,
-                           d_obs, O, Kv, obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g);
+                           d_obs, O, Kv, obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep);
+        VO_HIP_CHECK(hipGetLastError());
+    }
+    if (WITH_J && F) {
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((F * 42 + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g);
         VO_HIP_CHECK(hipGetLastError());
     }
     if (mem == VO_MEM_HOST) {
@@ -485,7 +540,7 @@ struct vo_ba {
     char *pool = nullptr;
     int64_t *ci = nullptr, *pi = nullptr;
     int *cam32 = nullptr, *pptr = nullptr, *pobs = nullptr, *flag = nullptr;
-    double *obs = nullptr, *r = nullptr, *Jp = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
+    double *obs = nullptr, *r = nullptr, *Jp = nullptr, *cam_rep = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
     double *x[2] = {nullptr, nullptr}, *cost[2] = {nullptr, nullptr}, *Hcc[2] = {nullptr, nullptr},
            *Hpp[2] = {nullptr, nullptr}, *Hcp[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};
     int cur = 0;
@@ -726,15 +781,17 @@ static int ba_linearize_into(vo_ba *ba, int slot)
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
     VO_HIP_CHECK(hipMemsetAsync(ba->cost[slot], 0, 8, ctx->stream));
     (void)np_;
-    if (ba->F) VO_HIP_CHECK(hipMemsetAsync(ba->Hcc[slot], 0, (size_t)ba->F * 288, ctx->stream));
-    if (ba->n) VO_HIP_CHECK(hipMemsetAsync(ba->g[slot], 0, (size_t)ba->n * 8, ctx->stream));  // camera part; the gather writes the rest
+    VO_HIP_CHECK(hipMemsetAsync(ba->cam_rep, 0, (size_t)BA_REPLICAS * ba->F * 42 * 8, ctx->stream));
     if (ba->O) {
         const unsigned blocks = (unsigned)((ba->O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL((ba_kernel<true, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P,
                            ba->ci, ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot],
-                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->Jp);
+                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->cam_rep, ba->Jp);
         VO_HIP_CHECK(hipGetLastError());
     }
+    hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((ba->F * 42 + 255) / 256), dim3(256), 0, ctx->stream, ba->F, ba->cam_rep,
+                       ba->Hcc[slot], ba->g[slot]);
+    VO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
                        ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot]);
     VO_HIP_CHECK(hipGetLastError());
@@ -807,7 +864,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         size_t tot = 0;
         auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
         const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
-                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48),
+                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take((size_t)BA_REPLICAS * F * 42 * 8),
                      o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8);
         size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
         for (int s = 0; s < 2; ++s) {
@@ -822,7 +879,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             char *b = ba->pool;
             ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
             ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
-            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->Dpinv = (double *)(b + o_dpi);
+            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
             ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
             for (int s = 0; s < 2; ++s) {
                 ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
