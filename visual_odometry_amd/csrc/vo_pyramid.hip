@@ -27,33 +27,57 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
+typedef unsigned short pd_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pd_u16x2 pd_pair(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_bit_cast(pd_u16x2, __builtin_amdgcn_perm(hi, lo, sel));
+}
+
 __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int sw, int sh,
                                                        int64_t spitch, int64_t sstride,
                                                        uint8_t *__restrict__ dst, int dw, int dh,
-                                                       int64_t dpitch, int64_t dstride)
+                                                       int64_t dpitch, int64_t dstride, int tiles_x, int tiles_y, int batch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[PD_IH * PD_IS];
     __shared__ __attribute__((aligned(16))) uint16_t hsum[PD_IH * PD_TW];
 
     const int t = threadIdx.x;
-    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
-    const uint8_t *simg = src + (int64_t)blockIdx.z * sstride;
-    uint8_t *dimg = dst + (int64_t)blockIdx.z * dstride;
+    // workgroups b and b+8 run on the same XCD (round-robin dispatch): give every XCD whole
+    // images, so the rows two neighbouring tiles share are fetched into one L2 only
+    const int per_image = tiles_x * tiles_y;
+    int bid = blockIdx.x, img, tl;
+    if ((batch & 7) == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        img = (j / per_image) * 8 + xcd;
+        tl = j % per_image;
+    } else {
+        img = bid / per_image;
+        tl = bid % per_image;
+    }
+    const int ox0 = (tl % tiles_x) * PD_TW, oy0 = (tl / tiles_x) * PD_TH;
+    const uint8_t *simg = src + (int64_t)img * sstride;
+    uint8_t *dimg = dst + (int64_t)img * dstride;
     const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2;
 
     // stage the input tile.  Interior tiles: unaligned 4-byte reads, consecutive lanes
-    // on consecutive dwords of a row (33 dwords cover the 131 bytes needed); tiles
-    // touching the image border read bytes with REFLECT_101 applied.
+    // on consecutive dwords of a row (33 dwords cover the 131 bytes needed), all five
+    // reads of a lane in flight before the first LDS store; tiles touching the image
+    // border read bytes with REFLECT_101 applied.
     const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + 4 * (PD_IS / 4) <= sw && iy0 + PD_IH <= sh;
     if (interior) {
         const uint8_t *base = simg + (int64_t)iy0 * spitch + ix0;
         uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
-        for (int idx = t; idx < PD_IH * (PD_IS / 4); idx += 256) {
-            int r = idx / (PD_IS / 4), c = idx - r * (PD_IS / 4);
-            uint32_t q;
-            __builtin_memcpy(&q, base + (int64_t)r * spitch + 4 * c, 4);
-            tile32[idx] = q;
+        constexpr int ITEMS = PD_IH * (PD_IS / 4), ROUNDS = (ITEMS + 255) / 256;
+        uint32_t q[ROUNDS];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int idx = min(t + 256 * k, ITEMS - 1);
+            const int r = (idx * 1986) >> 16, c = idx - r * (PD_IS / 4);   // idx / 33 for idx < 2560
+            __builtin_memcpy(&q[k], base + (int64_t)r * spitch + 4 * c, 4);
         }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) tile32[min(t + 256 * k, ITEMS - 1)] = q[k];
     } else {
         for (int idx = t; idx < PD_IH * PD_IW; idx += 256) {
             int r = idx / PD_IW, c = idx - r * PD_IW;
@@ -69,27 +93,46 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
     }
     __syncthreads();
 
-    // horizontal 5-tap on every staged row
-    for (int idx = t; idx < PD_IH * PD_TW; idx += 256) {
-        int r = idx / PD_TW, ox = idx - r * PD_TW;
-        const uint8_t *p = tile + r * PD_IS + 2 * ox;
-        hsum[idx] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
+    // horizontal 5-tap on every staged row, two adjacent outputs per item: the eight bytes
+    // b0..b7 at the pair's origin become 16-bit lane pairs {b0,b2} {b1,b3} {b2,b4} {b3,b5}
+    // {b4,b6}, so packed 16-bit math yields {h(ox), h(ox+1)} for one dword store
+    {
+        const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(tile);
+        uint32_t *hsum32 = reinterpret_cast<uint32_t *>(hsum);
+        for (int idx = t; idx < PD_IH * (PD_TW / 2); idx += 256) {
+            const int r = idx >> 5, pr = idx & 31;
+            const uint32_t lo = tile32[r * (PD_IS / 4) + pr], hi = tile32[r * (PD_IS / 4) + pr + 1];
+            const pd_u16x2 p0 = pd_pair(hi, lo, 0x0c020c00u), p1 = pd_pair(hi, lo, 0x0c030c01u),
+                           p2 = pd_pair(hi, lo, 0x0c040c02u), p3 = pd_pair(hi, lo, 0x0c050c03u),
+                           p4 = pd_pair(hi, lo, 0x0c060c04u);
+            const pd_u16x2 h = (p0 + p4) + (p1 + p3) * (unsigned short)4 + p2 * (unsigned short)6;
+            hsum32[idx] = __builtin_bit_cast(uint32_t, h);
+        }
     }
     __syncthreads();
 
-    // vertical 5-tap; thread -> 4 consecutive outputs of one row
-    const int oy = t >> 4, oxg = (t & 15) * 4;
-    const int gy = oy0 + oy, gx = ox0 + oxg;
-    if (gy < dh && gx < dw) {
-        const uint16_t *h0 = hsum + (2 * oy) * PD_TW + oxg;
-        uint32_t packed = 0;
+    // vertical 5-tap; thread -> 4 consecutive outputs of one row, packed 16-bit math
+    // (255 * 16 * 16 + 128 < 65536)
+    const int oxg = (t & 15) * 4, gx = ox0 + oxg;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int v = h0[k] + h0[4 * PD_TW + k] + 4 * (h0[PD_TW + k] + h0[3 * PD_TW + k]) + 6 * h0[2 * PD_TW + k];
-            packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
+    for (int half = 0; half < PD_TH / 16; ++half) {
+        const int oy = (t >> 4) + 16 * half, gy = oy0 + oy;
+        if (gy < dh && gx < dw) {
+            const uint2 *h0 = reinterpret_cast<const uint2 *>(hsum + (2 * oy) * PD_TW + oxg);
+            constexpr int RS = PD_TW / 4;  // row stride in uint2
+            const uint2 a0 = h0[0], a1 = h0[RS], a2 = h0[2 * RS], a3 = h0[3 * RS], a4 = h0[4 * RS];
+            uint32_t out2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const pd_u16x2 v0 = __builtin_bit_cast(pd_u16x2, k ? a0.y : a0.x), v1 = __builtin_bit_cast(pd_u16x2, k ? a1.y : a1.x),
+                               v2 = __builtin_bit_cast(pd_u16x2, k ? a2.y : a2.x), v3 = __builtin_bit_cast(pd_u16x2, k ? a3.y : a3.x),
+                               v4 = __builtin_bit_cast(pd_u16x2, k ? a4.y : a4.x);
+                const pd_u16x2 v = ((v0 + v4) + (v1 + v3) * (unsigned short)4 + v2 * (unsigned short)6 + (unsigned short)128) >> (unsigned short)8;
+                out2[k] = __builtin_bit_cast(uint32_t, v);
+            }
+            // bytes past dw land in the row's pitch padding
+            *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch + gx) = __builtin_amdgcn_perm(out2[1], out2[0], 0x06040200u);
         }
-        // bytes past dw land in the row's pitch padding
-        *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch + gx) = packed;
     }
 }
 
@@ -201,11 +244,12 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
         pyr->img_stride[0] = img_stride;
     }
     for (int l = 1; l <= pyr->max_level; ++l) {
-        dim3 grid((pyr->w[l] + PD_TW - 1) / PD_TW, (pyr->h[l] + PD_TH - 1) / PD_TH, pyr->batch);
-        VO_REQUIRE(grid.z <= 65535u, "vo_pyr_build: batch %d exceeds the grid limit 65535", pyr->batch);
-        hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, ctx->stream, pyr->lvl[l - 1], pyr->w[l - 1], pyr->h[l - 1],
-                           pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l], pyr->h[l], pyr->pitch[l],
-                           pyr->img_stride[l]);
+        const int tiles_x = (pyr->w[l] + PD_TW - 1) / PD_TW, tiles_y = (pyr->h[l] + PD_TH - 1) / PD_TH;
+        const int64_t blocks = (int64_t)tiles_x * tiles_y * pyr->batch;
+        VO_REQUIRE(blocks <= 0x7fffffff, "vo_pyr_build: %lld tiles exceed the grid limit", (long long)blocks);
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pyr->lvl[l - 1], pyr->w[l - 1],
+                           pyr->h[l - 1], pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l], pyr->h[l],
+                           pyr->pitch[l], pyr->img_stride[l], tiles_x, tiles_y, pyr->batch);
     }
     VO_HIP_CHECK(hipGetLastError());
     pyr->built = true;
