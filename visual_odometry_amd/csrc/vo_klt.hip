@@ -20,6 +20,7 @@
 // system and the right-hand side are reduced over the wave with DPP adds; every
 // branch is wave-uniform.
 #include "vo_internal.h"
+#include <stdlib.h>
 
 #define KLT_WIN 21
 #define KLT_HALF 10.0f
@@ -395,6 +396,281 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant with three keypoints per wavefront: lane l < 63 owns window column
+// l % 21 of keypoint l / 21 and walks all 21 rows of it, so the per-iteration
+// work that does not depend on the window size (bilinear weights, the 2x2 solve,
+// the stopping tests, loop control) is issued once for three keypoints.  Sums over
+// a keypoint's 21 lanes come from a DPP prefix scan over the wave and two
+// ds_bpermute reads of the scan at the group's ends.  The template keeps
+// 256 - 512*I per sample and the derivatives as int16 pairs of vertically
+// adjacent samples, matched by pairs of residuals so that v_dot2_i32_i16
+// accumulates b1 and b2 exactly in int32.
+// ---------------------------------------------------------------------------
+#define K3_S 27                        // tile row stride (dwords)
+#define K3_REGION (JT_ROWS * K3_S)     // one keypoint's tile region (dwords)
+#define K3_WAVES 4
+#define K3_KP_WAVE 3
+#define K3_KP_BLOCK (K3_WAVES * K3_KP_WAVE)
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_fz(float v)
+{
+    // lanes without a valid source, or masked out, see 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Sum of v over the 21 lanes of this lane's keypoint, in every lane of the group.
+// e_addr / s_addr: byte addresses (lane * 4) of the group's last lane and of the lane
+// before its first one; first: the group starts at lane 0.
+__device__ __forceinline__ float group_sum21(float v, int e_addr, int s_addr, bool first)
+{
+    float p = v + dpp_fz<0x111, 0xf, 0xf>(v);      // row_shr:1
+    p += dpp_fz<0x112, 0xf, 0xf>(v);               // row_shr:2
+    p += dpp_fz<0x113, 0xf, 0xf>(v);               // row_shr:3
+    // masked steps as single DPP adds: lanes outside the masks keep p
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+                 : "+v"(p));
+    const float e = __int_as_float(__builtin_amdgcn_ds_bpermute(e_addr, __float_as_int(p)));
+    const float s = __int_as_float(__builtin_amdgcn_ds_bpermute(s_addr, __float_as_int(p)));
+    return e - (first ? 0.f : s);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint32_t wb, uint32_t wtd, uint32_t wbd,
+                                            int ipx, int ipy, int col, int w, int h, uint32_t (&Ic)[21],
+                                            uint32_t (&IxP)[11], uint32_t (&IyP)[11], int &a11, int &a12, int &a22)
+{
+    // rows r = 0..23 of the tile; derivative row k = r - 2 (k = 0..21) sits at tile row k + 1;
+    // sample j (0..20) interpolates rows j, j + 1 of the derivative / centre-pixel rows
+    s16x2 h0a, h0b, h1a, h1b;
+    uint32_t prev_centre = 0, pr_k1 = 0, dx_k1 = 0, dy_k1 = 0;
+    int ixd_even = 0, iyd_even = 0;
+    uint32_t cm = 0xffffffffu;
+    if (MASKED)
+        cm = ((unsigned)(ipx + col) < (unsigned)w ? 0xffffu : 0u) | ((unsigned)(ipx + col + 1) < (unsigned)w ? 0xffff0000u : 0u);
+    a11 = 0; a12 = 0; a22 = 0;
+#pragma unroll
+    for (int r = 0; r < 24; ++r) {
+        const uint32_t q0 = t[r * K3_S], q1 = t[r * K3_S + 1], q2 = t[r * K3_S + 2];
+        const u16x2 pl = __builtin_bit_cast(u16x2, q0), pc = __builtin_bit_cast(u16x2, q1), prt = __builtin_bit_cast(u16x2, q2);
+        const s16x2 h0c = __builtin_bit_cast(s16x2, (u16x2)(prt - pl));
+        const s16x2 h1c = __builtin_bit_cast(s16x2, (u16x2)((pl + prt) * (unsigned short)3 + pc * (unsigned short)10));
+        if (r >= 2) {
+            const int k = r - 2;
+            uint32_t dx = __builtin_bit_cast(uint32_t, (s16x2)((h0a + h0c) * (short)3 + h0b * (short)10));
+            uint32_t dy = __builtin_bit_cast(uint32_t, (s16x2)(h1c - h1a));
+            if (MASKED) {
+                const uint32_t m = (unsigned)(ipy + k) < (unsigned)h ? cm : 0u;
+                dx &= m;
+                dy &= m;
+            }
+            const uint32_t pr_k = prev_centre;   // centre pairs of tile row k + 1
+            if (k >= 1) {
+                const int j = k - 1;
+                const uint32_t si = udot2(pr_k1, wt, udot2(pr_k, wb, 1u << 8));   // 512 * I + rounding bits
+                const int ixd = sdot2(dx_k1, wtd, sdot2(dx, wbd, 1 << 13));       // Ix << 14
+                const int iyd = sdot2(dy_k1, wtd, sdot2(dy, wbd, 1 << 13));
+                Ic[j] = 256u - (si & ~0x1ffu);
+                if ((j & 1) == 0) {
+                    ixd_even = ixd; iyd_even = iyd;
+                    if (j == 20) {
+                        IxP[10] = (uint32_t)(ixd >> 14) & 0xffffu;
+                        IyP[10] = (uint32_t)(iyd >> 14) & 0xffffu;
+                    }
+                } else {
+                    // {Ix_j-1, Ix_j} as int16 lanes: low half from the even sample, high half from this one
+                    IxP[j >> 1] = ((uint32_t)(ixd_even >> 14) & 0xffffu) | (((uint32_t)ixd << 2) & 0xffff0000u);
+                    IyP[j >> 1] = ((uint32_t)(iyd_even >> 14) & 0xffffu) | (((uint32_t)iyd << 2) & 0xffff0000u);
+                }
+                if ((j & 1) == 1 || j == 20) {
+                    const uint32_t xp = IxP[j >> 1], yp = IyP[j >> 1];
+                    a11 = sdot2(xp, xp, a11);
+                    a12 = sdot2(xp, yp, a12);
+                    a22 = sdot2(yp, yp, a22);
+                }
+            }
+            pr_k1 = pr_k; dx_k1 = dx; dy_k1 = dy;
+        }
+        h0a = h0b; h0b = h0c;
+        h1a = h1b; h1b = h1c;
+        prev_centre = q1;
+    }
+}
+
+__global__ __launch_bounds__(64 * K3_WAVES, 4) void klt_track3_kernel(KltArgs A)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[K3_WAVES * K3_KP_WAVE * K3_REGION];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = uniform(threadIdx.x >> 6);
+    int bid = blockIdx.x, img, kb;
+    if ((A.batch & 7) == 0) {
+        int xcd = bid & 7, j = bid >> 3;
+        img = (j / A.blocks_per_image) * 8 + xcd;
+        kb = j % A.blocks_per_image;
+    } else {
+        img = bid / A.blocks_per_image;
+        kb = bid % A.blocks_per_image;
+    }
+    const int kp_wave = kb * K3_KP_BLOCK + wid * K3_KP_WAVE;
+    if (kp_wave >= A.n) return;
+
+    // lane -> keypoint slot g and window column; lane 63 shadows lane 62 with zero derivative weights
+    const bool active = lane < 63;
+    const int g = lane < 21 ? 0 : (lane < 42 ? 1 : 2);
+    const int col = active ? lane - 21 * g : 20;
+    const bool have = kp_wave + g < A.n;
+    const int64_t pidx = (int64_t)img * A.n + min(kp_wave + g, A.n - 1);
+    const int e_addr = 4 * (21 * g + 20), s_addr = 4 * max(21 * g - 1, 0);
+    const bool first = g == 0;
+
+    uint32_t *lds_wave = lds_all + wid * (K3_KP_WAVE * K3_REGION);
+    const uint32_t *region = lds_wave + g * K3_REGION;
+
+    const float px0 = A.prev_pts[2 * pidx], py0 = A.prev_pts[2 * pidx + 1];
+    float outx = 0.f, outy = 0.f;
+    int status = 1;
+    float errv = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    for (int level = A.max_level; level >= 0; --level) {
+        const KltLevel L = A.lv[level];
+        const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
+        const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
+        const float sc = (float)(1. / (1 << level));
+        float px = px0 * sc, py = py0 * sc;
+        float nx, ny;
+        if (level == A.max_level) {
+            if (A.init_pts) { nx = A.init_pts[2 * pidx] * sc; ny = A.init_pts[2 * pidx + 1] * sc; }
+            else { nx = px; ny = py; }
+        } else {
+            nx = outx * 2.f; ny = outy * 2.f;
+        }
+        outx = nx; outy = ny;
+
+        px -= KLT_HALF; py -= KLT_HALF;
+        const float fpx = floorf(px), fpy = floorf(py);
+        const int ipx = (int)fpx, ipy = (int)fpy;
+        const bool lvl_ok = have && !(ipx < -KLT_WIN || ipx >= L.w || ipy < -KLT_WIN || ipy >= L.h);
+        if (have && !lvl_ok && level == 0) { status = 0; errv = 0.f; }
+        const unsigned long long okm = __ballot(lvl_ok);
+        if (okm == 0) continue;
+        uint32_t wt, wb;
+        bilinear_weights(px - fpx, py - fpy, wt, wb);
+
+        // ---- template ----
+        wave_sync();  // the regions may still be read as the coarser level's next-image tiles
+#pragma unroll
+        for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
+            if ((okm >> (21 * gi)) & 1ull) {
+                const int x0 = __builtin_amdgcn_readlane(ipx, 21 * gi) - 1, y0 = __builtin_amdgcn_readlane(ipy, 21 * gi) - 1;
+                stage_pairs<PT_ROWS, 23, K3_S>(lds_wave + gi * K3_REGION, pimg, L.ppitch, L.w, L.h, x0, y0, lane);
+            }
+        }
+        wave_sync();
+        uint32_t Ic[21], IxP[11], IyP[11];
+        int a11, a12, a22;
+        const uint32_t wtd = active ? wt : 0u, wbd = active ? wb : 0u;
+        const bool interior = ipx >= 0 && ipx + KLT_WIN < L.w && ipy >= 0 && ipy + KLT_WIN < L.h;
+        if (__ballot(lvl_ok && !interior) == 0)
+            k3_template<false>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
+        else
+            k3_template<true>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
+        const float A11 = group_sum21((float)a11, e_addr, s_addr, first) * FLT_SCALE;
+        const float A12 = group_sum21((float)a12, e_addr, s_addr, first) * FLT_SCALE;
+        const float A22 = group_sum21((float)a22, e_addr, s_addr, first) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - __builtin_amdgcn_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) *
+                             (1.f / (float)(2 * KLT_WIN * KLT_WIN));
+        if (lvl_ok) errv = minEig;
+        bool run = lvl_ok && !(minEig < A.min_eig || D < 1.1920928955078125e-07f);
+        if (lvl_ok && !run && level == 0) status = 0;
+        D = __builtin_amdgcn_rcpf(D);
+
+        // ---- Gauss-Newton iterations on the next image ----
+        nx -= KLT_HALF; ny -= KLT_HALF;
+        float pdx = 0.f, pdy = 0.f;
+        int ox = 0, oy = 0;
+        bool have_tile = false;
+        for (int j = 0; j < A.max_iters; ++j) {
+            if (__ballot(run) == 0) break;
+            const float fnx = floorf(nx), fny = floorf(ny);
+            const int inx = (int)fnx, iny = (int)fny;
+            if (run && (inx < -KLT_WIN || inx >= L.w || iny < -KLT_WIN || iny >= L.h)) {
+                if (level == 0) status = 0;
+                run = false;
+            }
+            int rx = inx - ox, ry = iny - oy;
+            const bool need = run && (!have_tile || rx < 0 || rx > 2 * KLT_M || ry < 0 || ry > 2 * KLT_M);
+            const unsigned long long needm = __ballot(need);
+            if (needm != 0) {
+                wave_sync();
+#pragma unroll
+                for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
+                    if ((needm >> (21 * gi)) & 1ull) {
+                        const int sx = __builtin_amdgcn_readlane(inx, 21 * gi) - KLT_M, sy = __builtin_amdgcn_readlane(iny, 21 * gi) - KLT_M;
+                        stage_pairs<JT_ROWS, JT_COLS, K3_S>(lds_wave + gi * K3_REGION, nimg, L.npitch, L.w, L.h, sx, sy, lane);
+                    }
+                }
+                wave_sync();
+                if (need) { ox = inx - KLT_M; oy = iny - KLT_M; rx = KLT_M; ry = KLT_M; have_tile = true; }
+            }
+            bilinear_weights(nx - fnx, ny - fny, wt, wb);
+
+            const uint32_t *jt = region + col + (run ? ry * K3_S + rx : 0);
+            uint32_t q[22];
+#pragma unroll
+            for (int k = 0; k < 22; ++k) q[k] = jt[k * K3_S];
+            int b1i = 0, b2i = 0;
+#pragma unroll
+            for (int p = 0; p < 11; ++p) {
+                // ((S + 256) >> 9) - I == (S + 256 - 512*I) >> 9 with an arithmetic shift; the residuals of two
+                // vertically adjacent samples share a dword as int16 lanes
+                const uint32_t s0 = udot2(q[2 * p], wt, udot2(q[2 * p + 1], wb, Ic[2 * p]));
+                uint32_t d2 = (uint32_t)((int)s0 >> 9) & 0xffffu;
+                if (2 * p + 1 < 21) {
+                    const uint32_t s1 = udot2(q[2 * p + 1], wt, udot2(q[2 * p + 2], wb, Ic[2 * p + 1]));
+                    d2 |= (s1 << 7) & 0xffff0000u;
+                }
+                b1i = sdot2(d2, IxP[p], b1i);
+                b2i = sdot2(d2, IyP[p], b2i);
+            }
+            const float b1 = group_sum21((float)b1i, e_addr, s_addr, first) * FLT_SCALE;
+            const float b2 = group_sum21((float)b2i, e_addr, s_addr, first) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            if (run) {
+                nx += dx; ny += dy;
+                outx = nx + KLT_HALF; outy = ny + KLT_HALF;
+                // delta.ddot(delta) <= eps2 is a float64 test; the float32 value decides it
+                // unless it falls inside a narrow bracket around eps2
+                const float dd = __builtin_fmaf(dx, dx, dy * dy);
+                bool conv = dd < A.eps2_lo;
+                if (!conv && !(dd > A.eps2_hi)) conv = (double)dx * dx + (double)dy * dy <= A.eps2;
+                // |x| < 0.01 (float64) for a float x  <=>  |x| <= 0x3C23D70A, the float just below 0.01
+                if (!conv && j > 0 && fabsf(dx + pdx) <= 0.00999999977648258209228515625f &&
+                    fabsf(dy + pdy) <= 0.00999999977648258209228515625f) {
+                    outx -= dx * 0.5f; outy -= dy * 0.5f;
+                    conv = true;
+                }
+                if (conv) run = false;
+                pdx = dx; pdy = dy;
+            }
+        }
+    }
+
+    if (have && active && col == 0) {
+        A.next_pts[2 * pidx] = outx;
+        A.next_pts[2 * pidx + 1] = outy;
+        A.status[pidx] = (uint8_t)status;
+        if (A.err) A.err[pidx] = errv;
+    }
+}
+
 static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
 {
     VO_REQUIRE(prev->built && next->built, "vo_klt_track: pyramids must be built first");
@@ -419,8 +695,27 @@ static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
     return VO_OK;
 }
 
+// VO_KLT_VARIANT=1 selects the one-keypoint-per-wave kernel, 3 the three-keypoints-per-wave kernel
+static int klt_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VO_KLT_VARIANT");
+        v = (e && e[0] == '3') ? 3 : 1;
+    }
+    return v;
+}
+
 static int launch_klt(vo_ctx *ctx, KltArgs &a)
 {
+    if (klt_variant() == 3) {
+        a.blocks_per_image = (a.n + K3_KP_BLOCK - 1) / K3_KP_BLOCK;
+        int64_t blocks3 = (int64_t)a.blocks_per_image * a.batch;
+        VO_REQUIRE(blocks3 < (1ll << 31), "vo_klt_track: too many keypoints (%lld workgroups)", (long long)blocks3);
+        hipLaunchKernelGGL(klt_track3_kernel, dim3((unsigned)blocks3), dim3(64 * K3_WAVES), 0, ctx->stream, a);
+        VO_HIP_CHECK(hipGetLastError());
+        return VO_OK;
+    }
     a.blocks_per_image = (a.n + KLT_WAVES - 1) / KLT_WAVES;
     int64_t blocks = (int64_t)a.blocks_per_image * a.batch;
     VO_REQUIRE(blocks < (1ll << 31), "vo_klt_track: too many keypoints (%lld workgroups)", (long long)blocks);
