@@ -13,6 +13,14 @@ POS_TOL = 0.05
 STATUS_AGREE = 0.995
 
 
+@pytest.fixture(params=["3", "1"], ids=["three-per-wave", "one-per-wave"])
+def klt_kernel(request, monkeypatch):
+    """Run a tracker test with each of the library's two LK kernels (the library reads the
+    environment variable at every launch; three keypoints per wavefront is its default)."""
+    monkeypatch.setenv("VO_KLT_VARIANT", request.param)
+    return request.param
+
+
 def _compare(oracle, ctx, img0, img1, pts, max_level=8, **kw):
     from visual_odometry_amd import hip
     h, w = img0.shape
@@ -53,7 +61,7 @@ def test_pyramid_device_input(oracle, ctx):
 
 
 @pytest.mark.parametrize("shape,n,seed", [((120, 160), 300, 1), ((240, 320), 500, 2), ((480, 640), 1000, 3)])
-def test_klt_parity_small(oracle, ctx, shape, n, seed):
+def test_klt_parity_small(oracle, ctx, klt_kernel, shape, n, seed):
     img0, img1, _ = synth.frame_pair(shape, seed=seed)
     pts = synth.uniform_keypoints(shape, n, seed=seed, margin=2)   # includes border windows
     agree, d, nb, _ = _compare(oracle, ctx, img0, img1, pts)
@@ -62,7 +70,7 @@ def test_klt_parity_small(oracle, ctx, shape, n, seed):
     assert d <= POS_TOL, d
 
 
-def test_klt_parity_kitti_shape(oracle, ctx):
+def test_klt_parity_kitti_shape(oracle, ctx, klt_kernel):
     img0, img1, _ = synth.frame_pair(synth.KITTI_SHAPE, seed=2021)
     pts = synth.uniform_keypoints(synth.KITTI_SHAPE, 2000, seed=0, margin=11)
     for max_level in (3, 8):
@@ -73,7 +81,7 @@ def test_klt_parity_kitti_shape(oracle, ctx):
         np.testing.assert_allclose(err[st == 1], re_[st == 1], rtol=1e-4)
 
 
-def test_klt_edge_points(oracle, ctx):
+def test_klt_edge_points(oracle, ctx, klt_kernel):
     """Points outside the image, on the border, and in flat regions."""
     img0, img1, _ = synth.frame_pair((120, 160), seed=4)
     img0 = img0.copy(); img1 = img1.copy()
@@ -86,7 +94,7 @@ def test_klt_edge_points(oracle, ctx):
     assert st[0] == 0 and st[1] == 0 and st[6] == 0
 
 
-def test_klt_batch_and_empty(oracle, ctx):
+def test_klt_batch_and_empty(oracle, ctx, klt_kernel):
     from visual_odometry_amd import hip
     B, shape, n = 16, (96, 128), 37        # batch multiple of 8 -> XCD-aware block mapping
     pairs = [synth.frame_pair(shape, seed=100 + b) for b in range(B)]
@@ -104,6 +112,10 @@ def test_klt_batch_and_empty(oracle, ctx):
     p0b = hip.Pyramid(ctx, 3, *shape).build(i0[:3]); p1b = hip.Pyramid(ctx, 3, *shape).build(i1[:3])
     out3, st3, _ = hip.klt_track(ctx, p0b, p1b, pts[:3])
     np.testing.assert_array_equal(st3, st[:3]); np.testing.assert_array_equal(out3, out[:3])
+    # fewer keypoints than one wavefront / one workgroup holds
+    for m in (1, 2, 4, 13):
+        om, sm, _ = hip.klt_track(ctx, p0b, p1b, np.ascontiguousarray(pts[:3, :m]))
+        np.testing.assert_array_equal(sm, st[:3, :m]); np.testing.assert_array_equal(om, out[:3, :m])
     # empty input
     o, s, e = hip.klt_track(ctx, p0b, p1b, np.zeros((3, 0, 2), np.float32))
     assert o.shape == (3, 0, 2) and s.shape == (3, 0)
@@ -125,7 +137,7 @@ def test_klt_device_buffers_match_host(ctx):
     np.testing.assert_array_equal(s.cpu().numpy()[0], st[0])
 
 
-def test_klt_forward_backward(oracle, ctx):
+def test_klt_forward_backward(oracle, ctx, klt_kernel):
     from visual_odometry_amd import hip
     shape, n = (240, 320), 400
     img0, img1, A = synth.frame_pair(shape, seed=11)

@@ -1,4 +1,6 @@
-// Pyramidal Lucas-Kanade tracker, one keypoint per 64-lane wavefront.
+// Pyramidal Lucas-Kanade tracker: klt_track3_kernel (three keypoints per 64-lane
+// wavefront, the default) and klt_track_kernel (one keypoint per wavefront), described
+// first.
 //
 // Semantics: cv.calcOpticalFlowPyrLK as the reference calls it
 // (vo_pipeline/poseEstimation.py:116-133): translation model, 21x21 window,
@@ -695,15 +697,12 @@ static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
     return VO_OK;
 }
 
-// VO_KLT_VARIANT=1 selects the one-keypoint-per-wave kernel, 3 the three-keypoints-per-wave kernel
+// Two tracker kernels with identical semantics: three keypoints per wavefront (default) and
+// one keypoint per wavefront (environment VO_KLT_VARIANT=1, kept for comparison runs).
 static int klt_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("VO_KLT_VARIANT");
-        v = (e && e[0] == '3') ? 3 : 1;
-    }
-    return v;
+    const char *e = getenv("VO_KLT_VARIANT");
+    return (e && e[0] == '1') ? 1 : 3;
 }
 
 static int launch_klt(vo_ctx *ctx, KltArgs &a)
