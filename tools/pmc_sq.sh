@@ -14,6 +14,6 @@ done
 python3 $REPO/tools/pmc_summary.py $OUT | python3 -c "
 import sys,json
 d=json.load(sys.stdin)
-k=d['klt_track_kernel']; w=k['SQ_WAVES']
+k=d.get('klt_track3_kernel') or d['klt_track_kernel']; w=k['SQ_WAVES']
 for c in sorted(k): print(c, round(k[c]/w,1) if c!='dispatches' else k[c])
 "

@@ -26,7 +26,7 @@
 
 #define KLT_WIN 21
 #define KLT_HALF 10.0f
-#define KLT_M 3                         // margin of the next-image tile (pixels)
+#define KLT_M 2                         // margin of the next-image tile (pixels)
 #define JT_S 35                         // next-image tile row stride (dwords), 7*35 % 32 == 21
 #define JT_ROWS (KLT_WIN + 1 + 2 * KLT_M)
 #define JT_COLS (KLT_WIN + 2 * KLT_M)   // pair columns
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
 // adjacent samples, matched by pairs of residuals so that v_dot2_i32_i16
 // accumulates b1 and b2 exactly in int32.
 // ---------------------------------------------------------------------------
-#define K3_S 27                        // tile row stride (dwords)
+#define K3_S 25                        // tile row stride (dwords)
 #define K3_REGION (JT_ROWS * K3_S)     // one keypoint's tile region (dwords)
 #define K3_WAVES 4
 #define K3_KP_WAVE 3
@@ -503,7 +503,7 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
     }
 }
 
-__global__ __launch_bounds__(64 * K3_WAVES, 4) void klt_track3_kernel(KltArgs A)
+__global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[K3_WAVES * K3_KP_WAVE * K3_REGION];
 
