@@ -148,6 +148,15 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b), c, false);
 }
 
+// a . b + c with c left intact: the three-operand encoding, so a chain that starts from a
+// constant needs no copy of it (the compiler picks the accumulate-in-place form plus a move)
+__device__ __forceinline__ int sdot2_keep(uint32_t a, uint32_t b, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
 // (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  When the tile's
 // column range lies inside the image an item is half a (reflected) row: one
@@ -451,6 +460,8 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
     s16x2 h0a, h0b, h1a, h1b;
     uint32_t prev_centre = 0, pr_k1 = 0, dx_k1 = 0, dy_k1 = 0;
     int ixd_even = 0, iyd_even = 0;
+    int bias = 1 << 13;
+    asm volatile("" : "+v"(bias));   // keep the rounding constant in one register
     uint32_t cm = 0xffffffffu;
     if (MASKED)
         cm = ((unsigned)(ipx + col) < (unsigned)w ? 0xffffu : 0u) | ((unsigned)(ipx + col + 1) < (unsigned)w ? 0xffff0000u : 0u);
@@ -474,8 +485,8 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
             if (k >= 1) {
                 const int j = k - 1;
                 const uint32_t si = udot2(pr_k1, wt, udot2(pr_k, wb, 1u << 8));   // 512 * I + rounding bits
-                const int ixd = sdot2(dx_k1, wtd, sdot2(dx, wbd, 1 << 13));       // Ix << 14
-                const int iyd = sdot2(dy_k1, wtd, sdot2(dy, wbd, 1 << 13));
+                const int ixd = sdot2(dx_k1, wtd, sdot2_keep(dx, wbd, bias));     // Ix << 14
+                const int iyd = sdot2(dy_k1, wtd, sdot2_keep(dy, wbd, bias));
                 Ic[j] = 256u - (si & ~0x1ffu);
                 if ((j & 1) == 0) {
                     ixd_even = ixd; iyd_even = iyd;
