@@ -190,7 +190,7 @@ def main():
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                if rec.get("streams_per_gpu") == S and rec.get("kernel") == "klt_track_kernel":
+                if rec.get("streams_per_gpu") == S and rec.get("kernel") == "klt_track3_kernel":
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -205,7 +205,7 @@ def main():
                        "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R,
                        "distinct_streams": (args.distinct if args.distinct and args.distinct < S else S) * world,
                        "tracked_fraction": tracked_frac, "parallelism": f"stream-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "klt_track_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "klt_track3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": klt_ms, "bytes_per_frame_kernel": klt_bytes, "bytes_per_frame_path": path_bytes,
                          "path_achieved": path_bytes * fps / world / 1e9},

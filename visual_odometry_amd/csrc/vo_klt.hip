@@ -537,14 +537,15 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
     const int g = lane < 21 ? 0 : (lane < 42 ? 1 : 2);
     const int col = active ? lane - 21 * g : 20;
     const bool have = kp_wave + g < A.n;
-    const int64_t pidx = (int64_t)img * A.n + min(kp_wave + g, A.n - 1);
+    // index of this lane's keypoint (the launch checks that batch * n fits 31 bits); kept as one
+    // register, positions are re-read per level rather than held
+    const int pidx = img * A.n + min(kp_wave + g, A.n - 1);
     const int e_addr = 4 * (21 * g + 20), s_addr = 4 * max(21 * g - 1, 0);
     const bool first = g == 0;
 
     uint32_t *lds_wave = lds_all + wid * (K3_KP_WAVE * K3_REGION);
     const uint32_t *region = lds_wave + g * K3_REGION;
 
-    const float px0 = A.prev_pts[2 * pidx], py0 = A.prev_pts[2 * pidx + 1];
     float outx = 0.f, outy = 0.f;
     int status = 1;
     float errv = 0.f;
@@ -555,10 +556,14 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
         const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
         const float sc = (float)(1. / (1 << level));
-        float px = px0 * sc, py = py0 * sc;
+        // the barrier keeps the 64-bit addresses below from being hoisted out of the level loop,
+        // where they would occupy registers for the whole kernel
+        int pi = pidx;
+        asm volatile("" : "+v"(pi));
+        float px = A.prev_pts[2 * (int64_t)pi] * sc, py = A.prev_pts[2 * (int64_t)pi + 1] * sc;
         float nx, ny;
         if (level == A.max_level) {
-            if (A.init_pts) { nx = A.init_pts[2 * pidx] * sc; ny = A.init_pts[2 * pidx + 1] * sc; }
+            if (A.init_pts) { nx = A.init_pts[2 * (int64_t)pi] * sc; ny = A.init_pts[2 * (int64_t)pi + 1] * sc; }
             else { nx = px; ny = py; }
         } else {
             nx = outx * 2.f; ny = outy * 2.f;
@@ -677,8 +682,8 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
     }
 
     if (have && active && col == 0) {
-        A.next_pts[2 * pidx] = outx;
-        A.next_pts[2 * pidx + 1] = outy;
+        A.next_pts[2 * (int64_t)pidx] = outx;
+        A.next_pts[2 * (int64_t)pidx + 1] = outy;
         A.status[pidx] = (uint8_t)status;
         if (A.err) A.err[pidx] = errv;
     }
@@ -720,6 +725,7 @@ static int launch_klt(vo_ctx *ctx, KltArgs &a)
 {
     if (klt_variant() == 3) {
         a.blocks_per_image = (a.n + K3_KP_BLOCK - 1) / K3_KP_BLOCK;
+        VO_REQUIRE((int64_t)a.n * a.batch < (1ll << 30), "vo_klt_track: too many keypoints (%lld)", (long long)a.n * a.batch);
         int64_t blocks3 = (int64_t)a.blocks_per_image * a.batch;
         VO_REQUIRE(blocks3 < (1ll << 31), "vo_klt_track: too many keypoints (%lld workgroups)", (long long)blocks3);
         hipLaunchKernelGGL(klt_track3_kernel, dim3((unsigned)blocks3), dim3(64 * K3_WAVES), 0, ctx->stream, a);
