@@ -120,6 +120,9 @@ void vo_or_scharr(const uint8_t *src, int w, int h, int stride, int16_t *dst)
  * (keypoint, level) pairs that reached the iteration loop */
 static long g_iters, g_levels;
 void vo_or_klt_stats(long *iters, long *levels) { *iters = g_iters; *levels = g_levels; }
+/* optional per-keypoint log of Gauss-Newton iterations, log[p * 16 + level]; NULL switches it off */
+static int *g_iter_log;
+void vo_or_klt_set_iter_log(int *log) { g_iter_log = log; }
 
 typedef struct {
     int w, h;
@@ -263,6 +266,7 @@ int vo_or_klt(const uint8_t *img0, const uint8_t *img1, int w, int h, int stride
             ++g_levels;
             for (int j = 0; j < max_iters; ++j) {
                 ++g_iters;
+                if (g_iter_log) ++g_iter_log[p * 16 + level];
                 int inx = cv_floor(nx), iny = cv_floor(ny);
                 if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
                     if (level == 0) status[p] = 0;
