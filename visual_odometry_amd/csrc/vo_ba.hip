@@ -184,11 +184,12 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
             for (int a = 0; a < 6; ++a) Jp_out[6 * (int64_t)i + a] = Jp[a];
         }
     } else if (active) {  // point blocks: per-lane atomics
+        // upper triangle only; ba_cam_sum_kernel mirrors it afterwards
         double *hp = Hpp + 9 * p, *gp = g + 6 * (int64_t)F + 3 * p;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) unsafeAtomicAdd(hp + a * 3 + b, Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b]);
+            for (int b = a; b < 3; ++b) unsafeAtomicAdd(hp + a * 3 + b, Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b]);
             unsafeAtomicAdd(gp + a, Jp[a] * rr[0] + Jp[3 + a] * rr[1]);
         }
     }
@@ -253,11 +254,16 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
     }
 }
 
-// Hcc[c] and g[6c..6c+5] = sum over the replicas filled by ba_kernel (overwrites both).
+// Hcc[c] and g[6c..6c+5] = sum over the replicas filled by ba_kernel (overwrites both); with
+// Hpp given, the lower triangles of the landmark blocks are filled from the upper ones.
 __global__ __launch_bounds__(256) void ba_cam_sum_kernel(int F, const double *__restrict__ cam_rep, double *__restrict__ Hcc,
-                                                         double *__restrict__ g)
+                                                         double *__restrict__ g, int P, double *__restrict__ Hpp)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (Hpp && t < P) {
+        double *hp = Hpp + 9 * (int64_t)t;
+        hp[3] = hp[1]; hp[6] = hp[2]; hp[7] = hp[5];
+    }
     if (t >= F * 42) return;
     double s = 0;
 #pragma unroll
@@ -329,8 +335,9 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
                            d_obs, O, Kv, obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep);
         VO_HIP_CHECK(hipGetLastError());
     }
-    if (WITH_J && F) {
-        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((F * 42 + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g);
+    if (WITH_J && (F || P)) {
+        const int work = F * 42 > P ? F * 42 : P;
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, P, d_Hpp);
         VO_HIP_CHECK(hipGetLastError());
     }
     if (mem == VO_MEM_HOST) {
@@ -790,7 +797,7 @@ static int ba_linearize_into(vo_ba *ba, int slot)
         VO_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((ba->F * 42 + 255) / 256), dim3(256), 0, ctx->stream, ba->F, ba->cam_rep,
-                       ba->Hcc[slot], ba->g[slot]);
+                       ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
                        ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot]);
