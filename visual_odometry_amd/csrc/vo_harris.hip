@@ -5,8 +5,8 @@
 // float32 Sobel 3x3 scaled by 1/8 (REFLECT_101), 2x2 un-normalised box sum of
 // the derivative products with offsets {-1,0} (REFLECT_101 on the product maps),
 // R = a*c - b*b - k*(a+c)^2; mode 1 = min-eigenvalue (Shi-Tomasi) response.
-// One workgroup stages a (8+3)x(32+3) image tile in LDS, derives the 9x33
-// derivative tile from it and emits 8x32 responses; image bytes are read once
+// One workgroup stages a (16+3)x(64+3) image tile in LDS, derives the 17x65
+// derivative tile from it and emits 16x64 responses; image bytes are read once
 // from HBM per tile (+halo), the response is written once.
 //
 // NMS/top-K: per image (1) max reduction, (2) local maxima above rel_thresh*max
@@ -18,8 +18,8 @@
 #include "vo_internal.h"
 #include <limits.h>
 
-#define HR_TW 32
-#define HR_TH 8
+#define HR_TW 64
+#define HR_TH 16
 #define HR_IW (HR_TW + 3)
 #define HR_IH (HR_TH + 3)
 #define HR_DW (HR_TW + 1)
@@ -34,6 +34,21 @@ __device__ __forceinline__ int refl1(int i, int n)
     return min(max(i, 0), n - 1);
 }
 
+__device__ __forceinline__ float harris_value(float a, float b, float c, float k, int mode)
+{
+    if (mode == 0) {
+        float ac_bb = a * c - b * b;
+        float ac = a + c;
+        return ac_bb - k * ac * ac;
+    }
+    float ha = a * 0.5f, hc = c * 0.5f;
+    return (ha + hc) - sqrtf((ha - hc) * (ha - hc) + b * b);
+}
+
+// One workgroup: 64 x 16 responses.  The (16+3) x (64+3) image tile is staged as floats (all
+// reads of a lane in flight before the first LDS store), the 17 x 65 Sobel derivatives are
+// formed from it, and every lane finishes four horizontally adjacent responses, which it
+// stores as 16 bytes.
 __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__restrict__ img, int w, int h,
                                                               int64_t pitch, int64_t istride, float k, int mode,
                                                               float *__restrict__ R)
@@ -46,10 +61,21 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
     const uint8_t *src = img + (int64_t)blockIdx.z * istride;
     float *dst = R + (int64_t)blockIdx.z * w * h;
 
-    for (int idx = t; idx < HR_IH * HR_IW; idx += 256) {
-        int r = idx / HR_IW, c = idx - r * HR_IW;
-        int y = refl1(y0 - 2 + r, h), x = refl1(x0 - 2 + c, w);
-        tile[r][c] = (float)src[(int64_t)y * pitch + x];
+    {
+        constexpr int ITEMS = HR_IH * HR_IW, ROUNDS = (ITEMS + 255) / 256;
+        uint8_t v[ROUNDS];
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int idx = min(t + 256 * q, ITEMS - 1);
+            const int r = idx / HR_IW, c = idx - r * HR_IW;
+            v[q] = src[(int64_t)refl1(y0 - 2 + r, h) * pitch + refl1(x0 - 2 + c, w)];
+        }
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int idx = min(t + 256 * q, ITEMS - 1);
+            const int r = idx / HR_IW, c = idx - r * HR_IW;
+            tile[r][c] = (float)v[q];
+        }
     }
     __syncthreads();
     for (int idx = t; idx < HR_DH * HR_DW; idx += 256) {
@@ -68,27 +94,26 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
         dys[r][c] = dy;
     }
     __syncthreads();
-    const int tx = t & (HR_TW - 1), ty = t >> 5;
+    const int tx = (t & 15) * 4, ty = t >> 4;
     const int gx = x0 + tx, gy = y0 + ty;
     if (gx >= w || gy >= h) return;
-    float a, b, c;
-    {
-        float ax = dxs[ty][tx], ay = dys[ty][tx], bx = dxs[ty][tx + 1], by = dys[ty][tx + 1];
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a, b, c;
+        float ax = dxs[ty][tx + j], ay = dys[ty][tx + j], bx = dxs[ty][tx + j + 1], by = dys[ty][tx + j + 1];
         a = ax * ax + bx * bx; b = ax * ay + bx * by; c = ay * ay + by * by;
-        ax = dxs[ty + 1][tx]; ay = dys[ty + 1][tx]; bx = dxs[ty + 1][tx + 1]; by = dys[ty + 1][tx + 1];
+        ax = dxs[ty + 1][tx + j]; ay = dys[ty + 1][tx + j]; bx = dxs[ty + 1][tx + j + 1]; by = dys[ty + 1][tx + j + 1];
         float ra = ax * ax + bx * bx, rb = ax * ay + bx * by, rc = ay * ay + by * by;
         a = a + ra; b = b + rb; c = c + rc;
+        out[j] = harris_value(a, b, c, k, mode);
     }
-    float out;
-    if (mode == 0) {
-        float ac_bb = a * c - b * b;
-        float ac = a + c;
-        out = ac_bb - k * ac * ac;
+    float *o = dst + (int64_t)gy * w + gx;
+    if (gx + 3 < w) {
+        __builtin_memcpy(o, out, 16);
     } else {
-        float ha = a * 0.5f, hc = c * 0.5f;
-        out = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + b * b);
+        for (int j = 0; j < 4 && gx + j < w; ++j) o[j] = out[j];
     }
-    dst[(int64_t)gy * w + gx] = out;
 }
 
 __device__ __forceinline__ uint32_t ordered_key(float v)
