@@ -157,6 +157,17 @@ __device__ __forceinline__ int sdot2_keep(uint32_t a, uint32_t b, int c)
     return r;
 }
 
+// {low 16 bits of lo, bits [sh+15 : sh] of src}: the shifted value is written straight into the
+// upper half of the register (sub-dword destination select), so packing two residuals or two
+// derivatives into int16 lanes costs the two shifts and nothing else
+__device__ __forceinline__ uint32_t pack_hi_shr(uint32_t lo, uint32_t src, uint32_t sh)
+{
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(lo)
+        : "v"(sh), "v"(src));
+    return lo;
+}
+
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
 // (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  When the tile's
 // column range lies inside the image an item is half a (reflected) row: one
@@ -462,6 +473,8 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
     int ixd_even = 0, iyd_even = 0;
     int bias = 1 << 13;
     asm volatile("" : "+v"(bias));   // keep the rounding constant in one register
+    uint32_t sh14 = 14;
+    asm volatile("" : "+v"(sh14));
     uint32_t cm = 0xffffffffu;
     if (MASKED)
         cm = ((unsigned)(ipx + col) < (unsigned)w ? 0xffffu : 0u) | ((unsigned)(ipx + col + 1) < (unsigned)w ? 0xffff0000u : 0u);
@@ -496,8 +509,8 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
                     }
                 } else {
                     // {Ix_j-1, Ix_j} as int16 lanes: low half from the even sample, high half from this one
-                    IxP[j >> 1] = ((uint32_t)(ixd_even >> 14) & 0xffffu) | (((uint32_t)ixd << 2) & 0xffff0000u);
-                    IyP[j >> 1] = ((uint32_t)(iyd_even >> 14) & 0xffffu) | (((uint32_t)iyd << 2) & 0xffff0000u);
+                    IxP[j >> 1] = pack_hi_shr((uint32_t)(ixd_even >> 14), (uint32_t)ixd, sh14);
+                    IyP[j >> 1] = pack_hi_shr((uint32_t)(iyd_even >> 14), (uint32_t)iyd, sh14);
                 }
                 if ((j & 1) == 1 || j == 20) {
                     const uint32_t xp = IxP[j >> 1], yp = IyP[j >> 1];
@@ -644,15 +657,19 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
 #pragma unroll
             for (int k = 0; k < 22; ++k) q[k] = jt[k * K3_S];
             int b1i = 0, b2i = 0;
+            uint32_t sh9 = 9;
+            asm volatile("" : "+v"(sh9));
 #pragma unroll
             for (int p = 0; p < 11; ++p) {
                 // ((S + 256) >> 9) - I == (S + 256 - 512*I) >> 9 with an arithmetic shift; the residuals of two
                 // vertically adjacent samples share a dword as int16 lanes
                 const uint32_t s0 = udot2(q[2 * p], wt, udot2(q[2 * p + 1], wb, Ic[2 * p]));
-                uint32_t d2 = (uint32_t)((int)s0 >> 9) & 0xffffu;
+                uint32_t d2;
                 if (2 * p + 1 < 21) {
                     const uint32_t s1 = udot2(q[2 * p + 1], wt, udot2(q[2 * p + 2], wb, Ic[2 * p + 1]));
-                    d2 |= (s1 << 7) & 0xffff0000u;
+                    d2 = pack_hi_shr(s0 >> 9, s1, sh9);
+                } else {
+                    d2 = (s0 >> 9) & 0xffffu;
                 }
                 b1i = sdot2(d2, IxP[p], b1i);
                 b2i = sdot2(d2, IyP[p], b2i);
