@@ -79,17 +79,36 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) tile32[min(t + 256 * k, ITEMS - 1)] = q[k];
     } else {
-        for (int idx = t; idx < PD_IH * PD_IW; idx += 256) {
-            int r = idx / PD_IW, c = idx - r * PD_IW;
-            int y = iy0 + r, x = ix0 + c;
-            // positions needed only by outputs outside the image may fall outside the
-            // reflect range; clamp them (their results are never stored)
-            y = min(max(y, -(sh - 1)), 2 * sh - 2);
-            x = min(max(x, -(sw - 1)), 2 * sw - 2);
+        // tiles touching the image border: same dword items with the row reflected per item;
+        // only the dwords that straddle the left/right border fall back to four byte reads
+        // with REFLECT_101.  Positions needed only by outputs outside the image may fall
+        // outside the reflect range; they are clamped (their results are never stored).
+        uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
+        constexpr int ITEMS = PD_IH * (PD_IS / 4), ROUNDS = (ITEMS + 255) / 256;
+        uint32_t q[ROUNDS];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int idx = min(t + 256 * k, ITEMS - 1);
+            const int r = (idx * 1986) >> 16, c = idx - r * (PD_IS / 4);
+            int y = min(max(iy0 + r, -(sh - 1)), 2 * sh - 2);
             y = sh > 1 ? reflect101(y, sh) : 0;
-            x = sw > 1 ? reflect101(x, sw) : 0;
-            tile[r * PD_IS + c] = simg[(int64_t)y * spitch + x];
+            const uint8_t *row = simg + (int64_t)y * spitch;
+            const int x = ix0 + 4 * c;
+            if (x >= 0 && x + 3 < sw) {
+                __builtin_memcpy(&q[k], row + x, 4);
+            } else {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int xx = min(max(x + b, -(sw - 1)), 2 * sw - 2);
+                    xx = sw > 1 ? reflect101(xx, sw) : 0;
+                    v |= (uint32_t)row[xx] << (8 * b);
+                }
+                q[k] = v;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) tile32[min(t + 256 * k, ITEMS - 1)] = q[k];
     }
     __syncthreads();
 
