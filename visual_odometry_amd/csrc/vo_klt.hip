@@ -169,13 +169,12 @@ __device__ __forceinline__ uint32_t pack_hi_shr(uint32_t lo, uint32_t src, uint3
 }
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
-// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  When the tile's
-// column range lies inside the image an item is half a (reflected) row: one
-// unaligned 16-byte read yields 15 pairs through v_perm_b32, and the second half
-// starts G1 pixels in so that the two reads end exactly at the last pixel the tile
-// needs (the pairs both halves produce are written twice with the same value).
-// One item per lane covers the whole tile.  Tiles that straddle the left/right
-// border take a per-pair byte path.
+// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  An item is half a
+// (reflected) row: one unaligned 16-byte read yields 15 pairs through v_perm_b32, and
+// the second half starts G1 pixels in so that the two reads end exactly at the last
+// pixel the tile needs (the pairs both halves produce are written twice with the same
+// value).  One item per lane covers the whole tile.  Only items that straddle the
+// left/right image border read their sixteen bytes one by one.
 template <int ROWS, int PAIRS, int STRIDE>
 __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
                                             int x0, int y0, int lane)
@@ -185,32 +184,38 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
     static_assert(2 * ROWS <= 64, "one item per lane");
     static_assert(PAIRS <= STRIDE, "tile row too narrow");
     const unsigned pitch32 = (unsigned)pitch;
-    if ((x0 >= 0) && (x0 + PAIRS + 1 <= w)) {
-        // keep the per-lane item coordinates from being hoisted out of the level
-        // loop (they would stay live for the whole kernel)
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        const int idx = min(l, 2 * ROWS - 1);  // surplus lanes repeat the last item
-        const unsigned r = (unsigned)idx >> 1;
-        const unsigned g = (idx & 1) ? (unsigned)G1 : 0u;
-        const unsigned y = (unsigned)refl(y0 + (int)r, h);
-        uint32_t q[4];
-        __builtin_memcpy(q, img + x0 + (__umul24(y, pitch32) + g), 16);
-        uint32_t *d = lds + (__umul24(r, (unsigned)STRIDE) + g);
-#pragma unroll
-        for (int j = 0; j < 15; ++j) {
-            const int c = j >> 2, o = j & 3;
-            d[j] = o == 0   ? __builtin_amdgcn_perm(0u, q[c], 0x0c010c00u)
-                   : o == 1 ? __builtin_amdgcn_perm(0u, q[c], 0x0c020c01u)
-                   : o == 2 ? __builtin_amdgcn_perm(0u, q[c], 0x0c030c02u)
-                            : __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c040c03u);
-        }
+    // keep the per-lane item coordinates from being hoisted out of the level
+    // loop (they would stay live for the whole kernel)
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int idx = min(l, 2 * ROWS - 1);  // surplus lanes repeat the last item
+    const unsigned r = (unsigned)idx >> 1;
+    const unsigned g = (idx & 1) ? (unsigned)G1 : 0u;
+    const unsigned y = (unsigned)refl(y0 + (int)r, h);
+    const uint8_t *row = img + __umul24(y, pitch32);
+    const int xs = x0 + (int)g;            // first pixel of this item
+    uint32_t q[4];
+    if (xs >= 0 && xs + 16 <= w) {
+        __builtin_memcpy(q, row + xs, 16);
     } else {
-        for (int idx = lane; idx < ROWS * PAIRS; idx += 64) {
-            const int r = idx / PAIRS, c = idx - r * PAIRS;
-            const uint8_t *row = img + __umul24((unsigned)refl(y0 + r, h), pitch32);
-            lds[r * STRIDE + c] = (uint32_t)row[refl(x0 + c, w)] | ((uint32_t)row[refl(x0 + c + 1, w)] << 16);
+        // the item straddles the left or right image border: sixteen byte reads with
+        // BORDER_REFLECT_101, assembled into the same four dwords
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (uint32_t)row[refl(xs + 4 * c + b, w)] << (8 * b);
+            q[c] = v;
         }
+    }
+    uint32_t *d = lds + (__umul24(r, (unsigned)STRIDE) + g);
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const int c = j >> 2, o = j & 3;
+        d[j] = o == 0   ? __builtin_amdgcn_perm(0u, q[c], 0x0c010c00u)
+               : o == 1 ? __builtin_amdgcn_perm(0u, q[c], 0x0c020c01u)
+               : o == 2 ? __builtin_amdgcn_perm(0u, q[c], 0x0c030c02u)
+                        : __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c040c03u);
     }
 }
 
@@ -443,9 +448,9 @@ __device__ __forceinline__ float dpp_fz(float v)
 }
 
 // Sum of v over the 21 lanes of this lane's keypoint, in every lane of the group.
-// e_addr / s_addr: byte addresses (lane * 4) of the group's last lane and of the lane
-// before its first one; first: the group starts at lane 0.
-__device__ __forceinline__ float group_sum21(float v, int e_addr, int s_addr, bool first)
+// e_addr: byte address (lane * 4) of the group's last lane (the lane before its first one is
+// 84 bytes lower); first: the group starts at lane 0.
+__device__ __forceinline__ float group_sum21(float v, int e_addr, bool first)
 {
     float p = v + dpp_fz<0x111, 0xf, 0xf>(v);      // row_shr:1
     p += dpp_fz<0x112, 0xf, 0xf>(v);               // row_shr:2
@@ -457,7 +462,7 @@ __device__ __forceinline__ float group_sum21(float v, int e_addr, int s_addr, bo
                  "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
                  : "+v"(p));
     const float e = __int_as_float(__builtin_amdgcn_ds_bpermute(e_addr, __float_as_int(p)));
-    const float s = __int_as_float(__builtin_amdgcn_ds_bpermute(s_addr, __float_as_int(p)));
+    const float s = __int_as_float(__builtin_amdgcn_ds_bpermute(max(e_addr - 84, 0), __float_as_int(p)));
     return e - (first ? 0.f : s);
 }
 
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
     // index of this lane's keypoint (the launch checks that batch * n fits 31 bits); kept as one
     // register, positions are re-read per level rather than held
     const int pidx = img * A.n + min(kp_wave + g, A.n - 1);
-    const int e_addr = 4 * (21 * g + 20), s_addr = 4 * max(21 * g - 1, 0);
+    const int e_addr = 4 * (21 * g + 20);   // the lane before the group's first one is e_addr - 84 (groups 1, 2)
     const bool first = g == 0;
 
     uint32_t *lds_wave = lds_all + wid * (K3_KP_WAVE * K3_REGION);
@@ -611,9 +616,9 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
             k3_template<false>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
         else
             k3_template<true>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
-        const float A11 = group_sum21((float)a11, e_addr, s_addr, first) * FLT_SCALE;
-        const float A12 = group_sum21((float)a12, e_addr, s_addr, first) * FLT_SCALE;
-        const float A22 = group_sum21((float)a22, e_addr, s_addr, first) * FLT_SCALE;
+        const float A11 = group_sum21((float)a11, e_addr, first) * FLT_SCALE;
+        const float A12 = group_sum21((float)a12, e_addr, first) * FLT_SCALE;
+        const float A22 = group_sum21((float)a22, e_addr, first) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - __builtin_amdgcn_sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) *
                              (1.f / (float)(2 * KLT_WIN * KLT_WIN));
@@ -674,8 +679,8 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
                 b1i = sdot2(d2, IxP[p], b1i);
                 b2i = sdot2(d2, IyP[p], b2i);
             }
-            const float b1 = group_sum21((float)b1i, e_addr, s_addr, first) * FLT_SCALE;
-            const float b2 = group_sum21((float)b2i, e_addr, s_addr, first) * FLT_SCALE;
+            const float b1 = group_sum21((float)b1i, e_addr, first) * FLT_SCALE;
+            const float b2 = group_sum21((float)b2i, e_addr, first) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             if (run) {
