@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "csrc", "libvo_hip.so")
+# VO_HIP_LIB names another build of the same library (A/B timing of two kernel versions on one box)
+LIB_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(_DIR, "csrc", "libvo_hip.so")
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_f32p = ctypes.POINTER(ctypes.c_float)
