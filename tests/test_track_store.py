@@ -1,0 +1,132 @@
+"""Track store, frame queue and BA-window marshalling against vectors recorded from the
+reference's KeypointTrajectories / FrameQueue / ContinuousVO._bundle_adjustment
+(tests/golden/track_store.npz, written by tools/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd.utils.frameQueue import FrameQueue
+from visual_odometry_amd.vo_pipeline import continuousVO
+from visual_odometry_amd.vo_pipeline.frameState import FrameState
+from visual_odometry_amd.vo_pipeline.keypointTrajectory import KeypointTrajectories
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_store.npz"))
+
+
+def _replay(batch: bool) -> KeypointTrajectories:
+    """Replay the recorded operations one by one, or frame-wise through the batch calls."""
+    store = KeypointTrajectories()
+    ops, lms = GOLD["ops"], GOLD["landmarks"]
+    if not batch:
+        for kind, frame, traj, x, y, lid in ops:
+            pt = np.array([x, y], np.float32)
+            if kind == 0:
+                if lid >= 0:
+                    assert len(store.landmarks) == int(lid)
+                    store.landmarks.append(lms[int(lid)])
+                store.create_trajectory(int(frame), pt, np.eye(4), None if lid < 0 else int(lid))
+            else:
+                store.tracked_to(int(traj), int(frame), pt, np.eye(4))
+        return store
+    i = 0
+    while i < len(ops):     # maximal runs of one (kind, frame, has-landmark)
+        j = i
+        while j < len(ops) and ops[j, 0] == ops[i, 0] and ops[j, 1] == ops[i, 1] and (ops[j, 5] >= 0) == (ops[i, 5] >= 0):
+            j += 1
+        run = ops[i:j]
+        frame, pts = int(run[0, 1]), run[:, 3:5].astype(np.float32)
+        if run[0, 0] == 0:
+            lid = run[:, 5].astype(int)
+            if lid[0] >= 0:
+                store.landmarks.extend(lms[lid])
+                store.create_trajectories(frame, pts, np.eye(4), lid)
+            else:
+                store.create_trajectories(frame, pts, np.eye(4))
+        else:
+            store.tracked_to_many(run[:, 2].astype(int), frame, pts, np.eye(4))
+        i = j
+    return store
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_at_frame_matches_reference(batch):
+    store = _replay(batch)
+    assert store.latest_frame == 9
+    for frame in range(3, 10):
+        kp, traj, lm = store.at_frame(frame)
+        assert kp.dtype == np.float32 and traj.dtype == np.int32 and lm.dtype == np.float32
+        np.testing.assert_array_equal(traj, GOLD[f"f{frame}_traj"])
+        np.testing.assert_array_equal(kp, GOLD[f"f{frame}_kp"])
+        np.testing.assert_array_equal(lm, GOLD[f"f{frame}_lm"])
+    with pytest.raises(AssertionError):
+        store.at_frame(2)
+    # trajectory 12 was created without a landmark: on its frame, never returned
+    assert 12 in store.on_frame[3] and 12 not in store.traj2landmark and 12 not in GOLD["f3_traj"]
+    rec = store.trajectory(0)
+    assert rec.init_idx == 3 and len(rec.pts) == rec.final_idx - rec.init_idx + 1
+
+
+def test_store_edge_cases():
+    store = KeypointTrajectories()
+    store.landmarks.append([1, 2, 3])
+    _, t = store.create_trajectory(5, np.array([1.0, 2.0]), np.eye(4), 0)
+    store.tracked_to(t, 5, np.array([9.0, 9.0]), np.eye(4))       # same frame again: first point stays
+    np.testing.assert_array_equal(store.at_frame(5)[0], [[1.0, 2.0]])
+    store.tracked_to(t, 8, np.array([4.0, 5.0]), np.eye(4))       # gap: frames 6, 7 carry nothing
+    assert 6 not in store.on_frame and store.latest_frame == 8
+    assert [tuple(p) for p in store.trajectory(t).pts] == [(1, 2), (4, 5), (4, 5), (4, 5)]
+    store.landmarks[0] = [7, 8, 9]
+    np.testing.assert_array_equal(store.at_frame(8)[2], [[7, 8, 9]])
+    assert store.mean_trajectory_length() == 3.0 and len(store.get_active()) == 1
+    with pytest.raises(KeyError):
+        store.tracked_to(99, 9, np.zeros(2), np.eye(4))
+    store.create_trajectories(9, np.zeros((0, 2)), np.eye(4))       # empty batch registers nothing
+    assert 9 not in store.on_frame and store.latest_frame == 9
+
+
+def test_frame_queue():
+    q = FrameQueue(3)
+    for i in range(5):
+        q.add(FrameState(i, None, np.eye(4)))
+    assert q.length == 3 and q.get_head().idx == 4 and q.get(2).idx == 2
+    assert [f.idx for f in q] == [2, 3, 4] and [f.idx for f in q] == [2, 3, 4]
+    with pytest.raises(AssertionError):
+        FrameState(0, None, np.eye(3))
+    with pytest.raises(AssertionError):
+        FrameQueue(0)
+
+
+class _Capture:
+    def bundle_adjustment(self, M, landmarks, ci, pi, kp):
+        self.args = (M, landmarks, ci, pi, kp)
+        adj = M.astype(np.float64).copy()
+        adj[:, :, 3] += 0.25
+        return adj, landmarks.astype(np.float64) + 0.5
+
+
+def test_ba_window_marshalling_matches_reference():
+    vo = object.__new__(continuousVO.ContinuousVO)
+    vo.keypoint_trajectories = _replay(True)
+    vo.frame_queue = FrameQueue(50)
+    for f, T in enumerate(GOLD["win_queue_poses"]):
+        vo.frame_queue.add(FrameState(f, np.zeros((2, 2), np.uint8), T.copy()))
+    vo.keyframes = [vo.frame_queue.queue[int(k)] for k in GOLD["win_keyframes"]]
+    vo.bundle_adjustment = _Capture()
+    ret = vo._bundle_adjustment(9, GOLD["win_T"])
+    M, L, ci, pi, kp = vo.bundle_adjustment.args
+    for got, key in ((M, "win_M"), (L, "win_landmarks"), (ci, "win_ci"), (pi, "win_pi"), (kp, "win_kp")):
+        np.testing.assert_array_equal(got, GOLD[key])
+    assert M.dtype == np.float32 and L.dtype == np.float32 and kp.dtype == np.float32
+    np.testing.assert_array_equal(ret, GOLD["win_ret"])
+    np.testing.assert_array_equal(np.asarray([fs.pose for fs in vo.frame_queue.queue]), GOLD["win_poses_after"])
+    np.testing.assert_array_equal(vo.keypoint_trajectories.landmarks.array, GOLD["win_landmarks_after"])
+
+
+def test_window_indices():
+    ci, pi, order = continuousVO.window_indices([np.array([5, 6]), np.array([], int), np.array([6, 9, 5])])
+    np.testing.assert_array_equal(ci, [0, 0, 2, 2, 2])
+    np.testing.assert_array_equal(pi, [0, 1, 1, 2, 0])
+    np.testing.assert_array_equal(order, [5, 6, 9])
+    ci, pi, order = continuousVO.window_indices([np.array([], int)])
+    assert ci.size == pi.size == order.size == 0

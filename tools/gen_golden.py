@@ -15,6 +15,8 @@ Functions exercised (reference file:line):
   BootstrapInitializer._transform_matrix            vo_pipeline/bootstrap.py:76-138
   ContinuousVO._baseline_uncertainty                vo_pipeline/continuousVO.py:249-271
   utils.matrix.hom_inv / skew                       utils/matrix.py:4-40
+  KeypointTrajectories.create_trajectory / tracked_to / at_frame   vo_pipeline/keypointTrajectory.py:42-138
+  FrameQueue.add / get, ContinuousVO._bundle_adjustment            utils/frameQueue.py:20-30, continuousVO.py:273-344
 """
 import os
 import sys
@@ -127,6 +129,72 @@ def main():
                         uncertainty_none=bu_none, T0_inv=hom_inv(T0), skew_v=np.array([1.0, 2.0, 3.0]),
                         skew_m=skew(np.array([1.0, 2.0, 3.0])))
     print("baseline", bu, bu_none)
+
+    # ---- track store and BA window marshalling --------------------------------
+    # A seeded script of store operations is replayed on the reference's KeypointTrajectories;
+    # ops rows: (kind 0=create 1=tracked_to, frame, trajectory id or -1, x, y, landmark id or -1).
+    from vo_pipeline.keypointTrajectory import KeypointTrajectories
+    from vo_pipeline.frameState import FrameState
+    from utils.frameQueue import FrameQueue
+    rng = np.random.default_rng(9)
+    store = KeypointTrajectories()
+    ops, lms = [], []
+    alive = []
+    out = {}
+
+    def create(frame, with_landmark):
+        pt = rng.uniform(0, 600, 2).astype(np.float32)
+        lid = -1
+        if with_landmark:
+            lid = len(store.landmarks)
+            lm = rng.uniform(-5, 30, 3).astype(np.float32)
+            store.landmarks.append(lm); lms.append(lm)
+        _, t = store.create_trajectory(frame, pt, np.eye(4), None if lid < 0 else lid)
+        ops.append((0, frame, -1, pt[0], pt[1], lid)); alive.append(t)
+
+    for _ in range(12):
+        create(3, True)
+    create(3, False)
+    for frame in range(4, 10):
+        rng.shuffle(alive)
+        alive = [t for t in alive if rng.uniform() > 0.12]
+        for t in alive:
+            pt = rng.uniform(0, 600, 2).astype(np.float32)
+            store.tracked_to(t, frame, pt, np.eye(4))
+            ops.append((1, frame, t, pt[0], pt[1], -1))
+        if frame in (6, 8):
+            for _ in range(5):
+                create(frame, True)
+    for frame in range(3, 10):
+        kp, tr, lm = store.at_frame(frame)
+        out[f"f{frame}_kp"], out[f"f{frame}_traj"], out[f"f{frame}_lm"] = kp, tr, lm
+    out["ops"] = np.asarray(ops, np.float64)
+    out["landmarks"] = np.asarray(lms, np.float32)
+
+    class Capture:
+        def bundle_adjustment(self, M, landmarks, ci, pi, kp):
+            self.args = (M, landmarks, ci, pi, kp)
+            adj = M.astype(np.float64).copy(); adj[:, :, 3] += 0.25
+            return adj, landmarks.astype(np.float64) + 0.5
+
+    vo = object.__new__(ContinuousVO)
+    vo.keypoint_trajectories = store
+    vo.frame_queue = FrameQueue(50)
+    poses = []
+    for f in range(0, 9):
+        Tf = np.eye(4); Tf[:3, :3] = rodrigues(rng.normal(0, 0.02, 3)); Tf[:3, 3] = rng.normal(0, 1, 3)
+        poses.append(Tf)
+        vo.frame_queue.add(FrameState(f, np.zeros((2, 2), np.uint8), Tf.copy()))
+    vo.keyframes = [vo.frame_queue.queue[4], vo.frame_queue.queue[7]]     # keyframes at frames 4 and 7
+    vo.bundle_adjustment = Capture()
+    Tcur = np.eye(4); Tcur[:3, 3] = [0.3, -0.1, 2.0]
+    ret = vo._bundle_adjustment(9, Tcur)
+    M, L, ci, pi, kp = vo.bundle_adjustment.args
+    out.update(win_queue_poses=np.asarray(poses), win_T=Tcur, win_M=M, win_landmarks=L, win_ci=ci, win_pi=pi,
+               win_kp=kp, win_ret=ret, win_poses_after=np.asarray([fs.pose for fs in vo.frame_queue.queue]),
+               win_landmarks_after=np.asarray(store.landmarks, np.float64), win_keyframes=np.array([4, 7]))
+    np.savez_compressed(os.path.join(OUT, "track_store.npz"), **out)
+    print("track_store: ops", len(ops), "window O =", ci.size, "F =", M.shape[0], "P =", L.shape[0])
 
 
 if __name__ == "__main__":

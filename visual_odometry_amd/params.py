@@ -22,5 +22,9 @@ def for_dataset(dataset: str = "KITTI") -> SimpleNamespace:
     )
 
 
-_p = for_dataset("KITTI")
-globals().update(vars(_p))
+def use_dataset(dataset: str) -> None:
+    """Switch the module-level constants to `dataset` (the reference edits DATASET in params.py)."""
+    globals().update(vars(for_dataset(dataset)))
+
+
+use_dataset("KITTI")

@@ -146,3 +146,69 @@ def ba_problem(F=10, P=5000, K=K_KITTI, visibility=1.0, seed=0, obs_noise=0.5):
     x = np.hstack([(cams + rng.normal(0, 1e-3, cams.shape)).ravel(), (pts + rng.normal(0, 0.05, pts.shape)).ravel()])
     return dict(x=x, ci=np.concatenate(ci), pi=np.concatenate(pi), obs=np.concatenate(obs).astype(np.float32), K=Kd,
                 F=F, P=P)
+
+
+class BoxScene:
+    """Seeded piecewise-planar 3-D scene (back wall, ground, fronto-parallel box faces) seen by a
+    camera that mostly translates sideways, in the manner of the 640x480 parking sequence.
+    Frames are ray-cast: every pixel takes the nearest plane hit and samples that plane's
+    band-limited texture bilinearly, so image motion has true parallax and occlusion edges.
+
+    poses[i]: (4,4) float64 camera-to-world of frame i (frame 0 is the identity)."""
+
+    PPU = 32.0   # texture pixels per world unit
+
+    def __init__(self, n_frames=40, shape=PARKING_SHAPE, K=K_PARKING, seed=5, step=0.08, noise=1.0):
+        rng = np.random.default_rng(seed)
+        self.shape, self.K, self.noise = shape, np.asarray(K, np.float64), noise
+        self.rng = rng
+        x0, x1 = -14.0, 14.0 + n_frames * step
+        # (origin, u axis, v axis, extent along u, extent along v); hit = origin + a u + b v
+        self.planes = [
+            (np.array([x0, -9.0, 14.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), x1 - x0, 11.0),   # back wall
+            (np.array([x0, 1.6, 1.0]), np.array([1.0, 0, 0]), np.array([0, 0, 1.0]), x1 - x0, 13.0),     # ground
+        ]
+        x = x0 + 2.0
+        while x < x1 - 4.0:
+            wdt, hgt, z = rng.uniform(2.0, 4.0), rng.uniform(1.5, 3.0), rng.uniform(6.0, 10.5)
+            self.planes.append((np.array([x, 1.6 - hgt, z]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), wdt, hgt))
+            x += wdt + rng.uniform(1.0, 3.0)
+        self.tex = []
+        for (_, _, _, eu, ev) in self.planes:
+            hw = (int(np.ceil(ev * self.PPU)) + 2, int(np.ceil(eu * self.PPU)) + 2)
+            self.tex.append(texture(hw, rng, margin=0))
+        self.poses = []
+        for i in range(n_frames):
+            T = np.eye(4)
+            T[:3, :3] = rodrigues([0.004 * np.sin(0.21 * i), 0.010 * np.sin(0.13 * i), 0.003 * np.sin(0.17 * i)])
+            T[:3, 3] = [step * i, 0.02 * np.sin(0.3 * i), 0.15 * step * i]
+            self.poses.append(T)
+        self.poses = np.asarray(self.poses)
+
+    def render(self, i):
+        h, w = self.shape
+        T = self.poses[i]
+        R, C = T[:3, :3], T[:3, 3]
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+        rays = (np.linalg.inv(self.K) @ np.stack([xs.ravel(), ys.ravel(), np.ones(h * w)])).T @ R.T
+        best = np.full(h * w, np.inf)
+        img = np.full(h * w, 128.0)
+        for (o, u, v, eu, ev), tex in zip(self.planes, self.tex):
+            nrm = np.cross(u, v)
+            den = rays @ nrm
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s = ((o - C) @ nrm) / den
+                X = C + s[:, None] * rays - o
+            a, b = X @ u, X @ v
+            hit = (den != 0) & (s > 1e-6) & (s < best) & (a >= 0) & (a <= eu) & (b >= 0) & (b <= ev)
+            if hit.any():
+                img[hit] = ndimage.map_coordinates(tex, [b[hit] * self.PPU, a[hit] * self.PPU], order=1, mode="nearest")
+                best[hit] = s[hit]
+        img = img.reshape(h, w) + np.random.default_rng(1000 + i).normal(0, self.noise, (h, w))
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def frames(self):
+        """Iterator of (K float32, image uint8), the form the pipeline's Dataset carries."""
+        Kf = np.asarray(self.K, np.float32)
+        for i in range(len(self.poses)):
+            yield Kf, self.render(i)

@@ -1,12 +1,25 @@
-"""Marshalling between the track store and the hot-path operators -- the parts of
-the reference's ContinuousVO (vo_pipeline/continuousVO.py:157-344) that shape the
-arrays the kernels consume.  The orchestrator state machine itself is outside the
-accelerated path."""
-from typing import Dict, List, Sequence, Tuple
+"""ContinuousVO -- the caller of the hot path (reference: vo_pipeline/continuousVO.py:19-352):
+frame loop, keyframe decision, windowed bundle adjustment and re-bootstrap, plus the
+marshalling helpers that shape the arrays the kernels consume.  Every numeric operator it
+calls (KLT, PnP-RANSAC, two-view bootstrap, bundle adjustment) is the GPU drop-in of this
+package; the bookkeeping between them is numpy on whole frames."""
+import logging
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from .. import params
+from ..utils.frameQueue import FrameQueue
 from ..utils.matrix import hom_inv
+from .bootstrap import BootstrapInitializer
+from .bundleAdjustment import BundleAdjustment
+from .featureExtraction import ExtractorType, FeatureExtractor
+from .frameState import FrameState
+from .keypointTrajectory import KeypointTrajectories
+from .poseEstimation import AlgoMethod, PoseEstimation
+
+log = logging.getLogger(__name__)
 
 
 def filter_tracked(status: np.ndarray, tracked_pts: np.ndarray, *per_point: np.ndarray):
@@ -59,3 +72,183 @@ def assemble_ba_window(poses: Sequence[np.ndarray], per_frame: Sequence[Tuple[np
     order = sorted(traj2local, key=traj2local.get)
     return (P, np.asarray(lm, dtype=np.float32).reshape(-1, 3), np.asarray(ci, dtype=np.int64),
             np.asarray(pi, dtype=np.int64), np.asarray(kps, dtype=np.float32).reshape(-1, 2), order)
+
+
+def window_indices(traj_per_frame: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Observation indexing of a BA window (continuousVO.py:287-306) from the trajectory ids seen on
+    each window frame -> (camera_indices (O,) ascending, point_indices (O,), trajectory id of each
+    local landmark in order of first appearance)."""
+    counts = [len(t) for t in traj_per_frame]
+    ci = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    if ci.size == 0:
+        return ci, np.zeros(0, np.int64), np.zeros(0, np.int64)
+    flat = np.concatenate([np.asarray(t, np.int64) for t in traj_per_frame])
+    uniq, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    return ci, rank[inv].astype(np.int64), uniq[order]
+
+
+class ContinuousVO:
+    """Same constructor, attributes and step() protocol as the reference.  descriptorType /
+    matcherType are accepted for signature compatibility; correspondences always come from the
+    corner detector + KLT (SIFT and descriptor matching are not part of this build).
+
+    rescale_bootstrap: a re-bootstrap triangulates with a unit baseline (bootstrap.py:103-111).
+    With True (default) the new translation and landmarks are scaled so that the baseline equals the
+    one implied by `world_transform` -- the step the reference carries as commented-out code
+    (continuousVO.py:128-135) -- which keeps one world scale across keyframes; False reproduces
+    the reference's active code path."""
+
+    def __init__(self, dataset, descriptorType=ExtractorType.SIFT, matcherType=None, useKLT=True,
+                 algo_method=AlgoMethod.P3P, max_point_distance: int = 100, frames_to_skip: int = 10,
+                 frame_queue_size: int = 1000, rescale_bootstrap: bool = True) -> None:
+        self.dataset = dataset
+        self.descriptor = FeatureExtractor(descriptorType)
+        self.matcher = matcherType
+        self.useKLT = useKLT
+        self.poseEstimator = PoseEstimation(self.dataset.K, use_KLT=useKLT, algo_method_type=algo_method)
+        self.bundle_adjustment = BundleAdjustment(self.dataset.K)
+        assert frame_queue_size > 0
+        self.frame_queue = FrameQueue(frame_queue_size)
+        self.keyframes: List[FrameState] = []
+        self.K: Optional[np.ndarray] = None
+        self.max_point_distance = max_point_distance
+        self.frames_to_skip = frames_to_skip
+        self.rescale_bootstrap = rescale_bootstrap
+        self.keypoint_trajectories = KeypointTrajectories()
+        self.frame_idx = 0
+        self.bootstrap_idx: List[int] = []
+        self.inlier_count = 0
+
+    def step(self) -> Optional[FrameState]:
+        """Take the next frame: the first `frames_to_skip` frames are only queued, the next one
+        initialises the point cloud against the oldest queued frame, every later one is tracked.
+        Returns the newest FrameState, or None when the dataset is exhausted."""
+        try:
+            K, img = next(self.dataset.frames)
+        except StopIteration:
+            return None
+        if self.frame_idx < self.frames_to_skip:
+            self.K = K
+            self.frame_queue.add(FrameState(self.frame_idx, img, np.eye(4, dtype=np.float32)))
+        elif self.frame_idx == self.frames_to_skip:
+            self._init_bootstrap(self.frame_idx, img)
+        else:
+            self._process_frame(self.frame_idx, img)
+        self.frame_idx += 1
+        return self.frame_queue.get_head()
+
+    def _add_keyframe(self, frame_state: FrameState) -> None:
+        self.keyframes.append(frame_state)
+
+    def _init_bootstrap(self, idx: int, img: np.ndarray) -> None:
+        baseline = self.frame_queue.get(self.frames_to_skip - 1)
+        T = self._bootstrap(baseline, idx, img)
+        frame_state = FrameState(idx, img, T, is_key=True)
+        self.frame_queue.add(frame_state)
+        self._add_keyframe(frame_state)
+
+    def _bootstrap(self, baseline: FrameState, frame_idx: int, img: np.ndarray,
+                   world_transform: Optional[np.ndarray] = None) -> np.ndarray:
+        """Two-view initialisation between baseline and img; registers one trajectory per
+        triangulated point on frame_idx.  Returns the world -> camera transform of img."""
+        bootstrap = BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance)
+        T_rel = np.array(bootstrap.T)
+        landmarks = np.array(bootstrap.point_cloud)
+        if self.rescale_bootstrap and world_transform is not None:
+            rel = np.asarray(world_transform, np.float64) @ hom_inv(np.asarray(baseline.pose, np.float64))
+            scale = float(np.linalg.norm(rel[0:3, 3]))
+            if scale > 0:
+                T_rel[0:3, 3] *= scale
+                landmarks[:, 0:3] *= scale
+        T = T_rel @ baseline.pose
+        num_pts = landmarks.shape[0]
+        new_landmarks = (hom_inv(baseline.pose) @ landmarks.T).T
+        store = self.keypoint_trajectories
+        first = len(store.landmarks)
+        store.landmarks.extend(new_landmarks[:, 0:3])
+        store.create_trajectories(frame_idx, bootstrap.pts2[:, 0:2], T, np.arange(first, first + num_pts))
+        self.inlier_count = num_pts
+        return T
+
+    def _process_frame(self, frame_idx: int, img: np.ndarray) -> None:
+        store = self.keypoint_trajectories
+        prev_img = self.frame_queue.get_head().img
+        prev_keypoints, prev_trajectories, prev_landmarks = store.at_frame(store.latest_frame)
+
+        tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints)
+        tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
+                                                                      prev_trajectories)
+        if tracked_landmarks.shape[0] > 5:
+            T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
+            ratio = inlier_ratio(inliers, self.inlier_count)
+        else:
+            warnings.warn("too few points, forced bootstrap")
+            prev_keyframe = self.keyframes[-1]
+            T = self._bootstrap(prev_keyframe, frame_idx, img, world_transform=self.frame_queue.queue[-1].pose)
+            self.bootstrap_idx.append(frame_idx)
+            frame_state = FrameState(frame_idx, img, T, tracked_kps=tracked_pts.shape[0], is_key=True)
+            self.frame_queue.add(frame_state)
+            self.keyframes.append(frame_state)
+            return
+
+        keep = np.unique(inliers.ravel())       # ascending: the order the reference visits them in
+        store.tracked_to_many(trajectories[keep], frame_idx, tracked_pts[keep], T)
+
+        is_key = False
+        prev_keyframe = self.keyframes[-2] if len(self.keyframes) >= 2 else self.keyframes[-1]
+        uncertainty = self._baseline_uncertainty(prev_keyframe.pose, T, tracked_landmarks)
+        log.info("%d: tracked_pts: %5d, inlier_ratio: %.2f, baseline uncertainty: %.2f", frame_idx,
+                 tracked_pts.shape[0], ratio, uncertainty)
+        if uncertainty > params.MAX_BASELINE_UNCERTAINTY or ratio < params.MIN_INLIER_RATIO:
+            is_key = True
+            self._bundle_adjustment(frame_idx, T)
+            prev_keyframe = self.frame_queue.get(2)
+            T = self._bootstrap(prev_keyframe, frame_idx, img,
+                                world_transform=T if self.rescale_bootstrap else prev_keyframe.pose)
+            self.bootstrap_idx.append(frame_idx)
+
+        frame_state = FrameState(frame_idx, img, T, tracked_kps=tracked_pts.shape[0], is_key=is_key)
+        self.frame_queue.add(frame_state)
+        if is_key:
+            self.keyframes.append(frame_state)
+
+    def _baseline_uncertainty(self, T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray) -> float:
+        return baseline_uncertainty(T0, T1, landmarks)
+
+    def _ba_window(self, frame_idx: int, T: np.ndarray):
+        """Arrays of the BA window ending at frame_idx (continuousVO.py:273-313)."""
+        store = self.keypoint_trajectories
+        prev_keyframe = self.keyframes[max(-params.BUNDLE_ADJUSTMENT_KEYFRAME_LOOK_BACK, -len(self.keyframes))]
+        look_back = frame_idx - prev_keyframe.idx
+        if look_back >= self.frame_queue.size:
+            look_back = self.frame_queue.size - 1
+        poses, kps, trajs = [], [], []
+        for i in range(look_back + 1):
+            old_frame_idx = frame_idx - look_back + i
+            pose = T if old_frame_idx == frame_idx else self.frame_queue.get(look_back - i - 1).pose
+            poses.append(np.asarray(pose)[0:3, 0:4])
+            kp, traj, _ = store.at_frame(old_frame_idx)
+            kps.append(kp)
+            trajs.append(traj)
+        ci, pi, traj_of_point = window_indices(trajs)
+        landmark_ids = store.traj2landmark.lookup(traj_of_point)
+        return (look_back, np.asarray(poses, dtype=np.float32), store.landmarks.array[landmark_ids].astype(np.float32),
+                ci, pi, np.concatenate(kps).astype(np.float32).reshape(-1, 2), landmark_ids)
+
+    def _bundle_adjustment(self, frame_idx: int, T: np.ndarray) -> np.ndarray:
+        look_back, poses, landmarks, ci, pi, keypoints, landmark_ids = self._ba_window(frame_idx, T)
+        adjusted_poses, adjusted_landmarks = self.bundle_adjustment.bundle_adjustment(poses, landmarks, ci, pi, keypoints)
+        hom = np.zeros((adjusted_poses.shape[0], 4, 4), adjusted_poses.dtype)
+        hom[:, 0:3, :] = adjusted_poses
+        hom[:, 3, 3] = 1
+        for i in range(look_back):       # frames already in the queue; the current one is not yet
+            self.frame_queue.get(look_back - i - 1).pose = hom[i].copy()
+        self.keypoint_trajectories.landmarks.array[landmark_ids] = adjusted_landmarks
+        return hom[-1]
+
+    @staticmethod
+    def get_baseline_uncertainty(T: np.ndarray, point_cloud: np.ndarray) -> float:
+        return float(np.linalg.norm(T[0:3, 3]) / np.mean(point_cloud[:, 2]))
