@@ -158,6 +158,18 @@ int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, i
 int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, int width, float rel_thresh, int radius,
                 int K, float *xy, float *scores, int32_t *count, int mem);
 
+/* vo_detect_corners = vo_harris_response followed by vo_nms_topk on the same images,
+ * with identical results, in one call: the response map stays in a library-owned
+ * device buffer (no caller allocation, no host round trip) and its per-image maximum
+ * is reduced inside the response pass.  It stands in for the whole of
+ * FeatureExtractor.harris (vo_pipeline/featureExtraction.py:37-51) and supplies the
+ * Shi-Tomasi corners the bootstrap tracks (mode 1).  Arguments as in the two calls above.
+ */
+int vo_detect_corners(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
+                      int64_t img_stride, float k, int mode, float rel_thresh, int radius, int K, float *xy,
+                      float *scores, int32_t *count, int mem);
+
+
 /* ---- minimal solvers (model generators of the two RANSAC calls) ---------------
  * vo_p3p_solve: per sample of four 2D-3D pairs, the P3P pose of pairs 0..2 that
  * best reprojects pair 3 -- the candidate generator inside

@@ -81,3 +81,45 @@ def test_harris_device_path_feeds_tracker(oracle, ctx):
     assert np.abs(out[0].cpu().numpy()[ok] - ro[ok]).max() <= 0.05
     truth = rxy @ A[:, :2].T + A[:, 2]
     assert np.median(np.linalg.norm(ro[ok] - truth[ok], axis=1)) < 0.05
+
+
+@pytest.mark.parametrize("shape,K,radius,mode", [((60, 83), 50, 1, 1), ((376, 1241), 2000, 5, 1), ((376, 1241), 4096, 1, 0),
+                                                ((480, 640), 300, 8, 1), ((40, 40), 4096, 1, 0), ((3, 3), 4, 1, 1),
+                                                ((200, 333), 500, 12, 1), ((33, 70), 100, 3, 0), ((17, 129), 64, 7, 1),
+                                                ((64, 128), 400, 2, 1), ((100, 100), 300, 4, 0), ((90, 200), 300, 6, 1)])
+def test_detect_corners_identical(oracle, ctx, shape, K, radius, mode):
+    """vo_detect_corners (maximum reduced inside the response pass) against the oracle's response -> NMS -> top-K."""
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(3)
+    imgs = np.stack([synth.frame_pair(shape, seed=1)[0] if min(shape) > 30 else rng.integers(0, 256, shape, dtype=np.uint8),
+                     rng.integers(0, 256, shape, dtype=np.uint8)])
+    k = 0.1 if mode == 0 else 0.04
+    xy, sc, cnt = hip.detect_corners(ctx, imgs, K, 0.01, radius, k, mode)
+    for b in range(2):
+        rxy, rsc, m = oracle.nms_topk(oracle.harris_response(imgs[b], k, mode), K, 0.01, radius)
+        assert cnt[b] == m
+        np.testing.assert_array_equal(xy[b], rxy)
+        np.testing.assert_array_equal(sc[b], rsc)
+
+
+def test_detect_corners_device_batch_and_flat(oracle, ctx):
+    import torch
+    from visual_odometry_amd import hip
+    imgs = np.stack([synth.frame_pair(synth.KITTI_SHAPE, seed=s)[0] for s in range(9)])
+    imgs[4] = 77                                            # flat image: response 0 everywhere, nothing above 0.01 * 0
+    t = torch.from_numpy(imgs).cuda()
+    for rep in range(2):                                    # the second call reuses the candidate slots of the first
+        xy, sc, cnt = hip.detect_corners(ctx, t, 2000, 0.01, 5)
+        R = hip.harris_response(ctx, t, 0.04, hip.MIN_EIGEN)
+        xy2, sc2, cnt2 = hip.nms_topk(ctx, R, 2000, 0.01, 5)
+        ctx.sync()
+        assert torch.equal(cnt, cnt2) and torch.equal(xy, xy2) and torch.equal(sc, sc2)
+        assert int(cnt[4]) == 0 and int(cnt[0]) == 2000
+    # a strided view (every second image): row and image strides are honoured
+    xy3, _, cnt3 = hip.detect_corners(ctx, t[::2], 2000, 0.01, 5)
+    ctx.sync()
+    assert torch.equal(xy3, xy[::2]) and torch.equal(cnt3, cnt[::2])
+    with pytest.raises(ValueError):
+        hip.detect_corners(ctx, imgs, 5000, 0.01, 5)
+    with pytest.raises(ValueError):
+        hip.detect_corners(ctx, imgs, 100, 0.01, 0)

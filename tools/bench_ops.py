@@ -128,6 +128,11 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": nbytes * B / ((ms_r + ms_n) * 1e-3) / 1e9, "peak": HBM,
                              "unit": "GB/s", "frac": nbytes * B / ((ms_r + ms_n) * 1e-3) / 1e9 / HBM},
                 "cpu_oracle_ms_per_frame": cms, "cpu_cores": 1})
+    ms_f = timed(ctx, lambda: hip.detect_corners(ctx, timg, 2000, 0.01, 5, 0.04, hip.MIN_EIGEN))
+    out.append({"op": "detect_corners (response with fused max + NMS + top-K)", "workload": f"{B} frames 1241x376, Shi-Tomasi, top-2000, radius 5",
+                "ms": ms_f, "frames_per_s": B / (ms_f * 1e-3), "algorithmic_bytes_per_frame": nbytes,
+                "roofline": {"bound": "hbm", "achieved": nbytes * B / (ms_f * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
+                             "frac": nbytes * B / (ms_f * 1e-3) / 1e9 / HBM}})
     for o in out:
         print(json.dumps(o), flush=True)
 

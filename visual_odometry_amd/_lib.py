@@ -55,6 +55,9 @@ SIGNATURES = {
                                           c_vp, ctypes.c_int]),
     "vo_nms_topk": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                    ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_detect_corners": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                         ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int]),
     "vo_p3p_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, ctypes.c_int, c_vp, c_vp,
                                     ctypes.c_int]),
     "vo_seven_point_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp,

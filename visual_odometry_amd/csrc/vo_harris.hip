@@ -26,12 +26,31 @@
 #define HR_DH (HR_TH + 1)
 #define TOPK_MAX 4096
 #define TOPK_THREADS 1024
+// per-image maxima are kept MAXKEY_STRIDE words apart: atomics on neighbouring words queue up at one
+// memory channel (thousands of workgroups report to a few cache lines otherwise)
+#define MAXKEY_STRIDE 64
+
+// atomicMax that skips the atomic when the value cannot raise the maximum any more
+__device__ __forceinline__ void raise_max(uint32_t *slot, uint32_t v)
+{
+    if (v > __builtin_nontemporal_load(slot)) atomicMax(slot, v);
+}
 
 __device__ __forceinline__ int refl1(int i, int n)
 {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * n - 2 - i : i;
     return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ uint32_t ordered_key(float v)
+{
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
 __device__ __forceinline__ float harris_value(float a, float b, float c, float k, int mode)
@@ -51,9 +70,10 @@ __device__ __forceinline__ float harris_value(float a, float b, float c, float k
 // stores as 16 bytes.
 __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__restrict__ img, int w, int h,
                                                               int64_t pitch, int64_t istride, float k, int mode,
-                                                              float *__restrict__ R)
+                                                              float *__restrict__ R, uint32_t *__restrict__ maxkey)
 {
     __shared__ float tile[HR_IH][HR_IW + 1];
+    __shared__ uint32_t wave_max[4];
     __shared__ float dxs[HR_DH][HR_DW + 1];
     __shared__ float dys[HR_DH][HR_DW + 1];
     const int t = threadIdx.x;
@@ -96,8 +116,10 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
     __syncthreads();
     const int tx = (t & 15) * 4, ty = t >> 4;
     const int gx = x0 + tx, gy = y0 + ty;
-    if (gx >= w || gy >= h) return;
+    const bool inside = gx < w && gy < h;
+    if (!inside && !maxkey) return;
     float out[4];
+    uint32_t mk = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float a, b, c;
@@ -107,24 +129,27 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
         float ra = ax * ax + bx * bx, rb = ax * ay + bx * by, rc = ay * ay + by * by;
         a = a + ra; b = b + rb; c = c + rc;
         out[j] = harris_value(a, b, c, k, mode);
+        if (inside && gx + j < w) mk = max(mk, ordered_key(out[j]));
     }
-    float *o = dst + (int64_t)gy * w + gx;
-    if (gx + 3 < w) {
-        __builtin_memcpy(o, out, 16);
-    } else {
-        for (int j = 0; j < 4 && gx + j < w; ++j) o[j] = out[j];
+    if (inside) {
+        float *o = dst + (int64_t)gy * w + gx;
+        if (gx + 3 < w) {
+            __builtin_memcpy(o, out, 16);
+        } else {
+            for (int j = 0; j < 4 && gx + j < w; ++j) o[j] = out[j];
+        }
+    }
+    if (maxkey) {
+        // per-image maximum of the response (as ordered keys) for the detector's relative threshold:
+        // one atomic per workgroup
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, o));
+        if ((t & 63) == 0) wave_max[t >> 6] = mk;
+        __syncthreads();
+        if (t == 0) raise_max(&maxkey[blockIdx.z * MAXKEY_STRIDE], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
     }
 }
 
-__device__ __forceinline__ uint32_t ordered_key(float v)
-{
-    uint32_t u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_value(uint32_t k)
-{
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ R, int64_t npix, uint32_t *__restrict__ maxkey)
 {
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ 
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0)
-        atomicMax(&maxkey[blockIdx.y], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
+        raise_max(&maxkey[blockIdx.y * MAXKEY_STRIDE], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
 }
 
 #define NMS_TW 64
@@ -166,8 +191,8 @@ __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ 
 // earlier raster neighbour (rows above, left part of its own row) is strictly
 // smaller: an earlier neighbour wins ties.  Survivors leave as 64-bit keys
 // {ordered(R), ~raster index} in the tile's own slots of the candidate array
-// (survivors are more than `radius` apart, which bounds their number per tile; the
-// caller zero-fills the array and zero marks an empty slot).  RAD > 0 fixes the
+// (survivors are more than `radius` apart, which bounds their number per tile; zero
+// marks an empty slot).  RAD > 0 fixes the
 // radius at compile time (fully unrolled window loops); RAD == 0 takes it at run time.
 template <int RAD>
 __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__ R, int w, int h, int radius, float rel_thresh,
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__
         hm[yy * NMS_TW + lx] = m;
     }
     __syncthreads();
-    const float thr = rel_thresh * key_value(maxkey[b]);
+    const float thr = rel_thresh * key_value(maxkey[b * MAXKEY_STRIDE]);
     const int py0 = ly * 4;  // this lane finishes tile rows py0..py0+3 of column lx
     const float *hc = hm + lx;
 #pragma unroll
@@ -240,6 +265,12 @@ __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__
             if (slot < tile_slots)
                 cand[tile_id * tile_slots + slot] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
         }
+    }
+    __syncthreads();
+    {
+        // the tile's unused slots are marked empty here, so the candidate array needs no clearing
+        const int64_t tile_id = ((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int slot = s_n + threadIdx.x; slot < tile_slots; slot += 256) cand[tile_id * tile_slots + slot] = 0ull;
     }
 }
 
@@ -338,6 +369,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long 
     if (t == 0) count[b] = m;
 }
 
+
 extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
                                   int64_t img_stride, int block_size, int ksize, float k, int mode, float *R, int mem)
 {
@@ -368,12 +400,60 @@ extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, in
     }
     dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);
     VO_REQUIRE(grid.y <= 65535u, "vo_harris_response: image too tall");
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R);
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
+                       (uint32_t *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_HIP_CHECK(hipMemcpyAsync(R, d_R, npix * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
+    return VO_OK;
+}
+
+// Device part of the selection: (max of R unless have_max), tile NMS into per-tile candidate slots, top-K.
+// d_max: (batch) ordered keys MAXKEY_STRIDE words apart, zeroed by the caller and already complete when have_max is set.
+static int nms_select(vo_ctx *ctx, const float *d_R, int batch, int height, int width, float rel_thresh, int radius, int K,
+                      uint32_t *d_max, bool have_max, float *d_xy, float *d_sc, int *d_cnt)
+{
+    const size_t npix = (size_t)width * height;
+    // survivors are more than `radius` apart, so a 64x16 tile holds at most this many
+    const int tile_slots = ((NMS_TW + radius) / (radius + 1)) * ((NMS_TH + radius) / (radius + 1));
+    dim3 grid((width + NMS_TW - 1) / NMS_TW, (height + NMS_TH - 1) / NMS_TH, batch);
+    VO_REQUIRE(grid.y <= 65535u, "corner selection: image too tall");
+    const int cap = (int)(grid.x * grid.y) * tile_slots;  // candidate slots per image
+    int rc;
+    void *p;
+    if ((rc = vo_stage_reserve(ctx, 5, (size_t)batch * cap * 8, &p))) return rc;
+    unsigned long long *d_cand = (unsigned long long *)p;
+    if (!have_max) {
+        int mblocks = (int)((npix / 4 + 256 * 4 - 1) / (256 * 4));
+        if (mblocks > 512) mblocks = 512;
+        if (mblocks < 1) mblocks = 1;
+        hipLaunchKernelGGL(max_key_kernel, dim3(mblocks, batch), dim3(256), 0, ctx->stream, d_R, (int64_t)npix, d_max);
+    }
+    const size_t nms_lds = ((size_t)(NMS_TH + 2 * radius) * (NMS_TW + 2 * radius) + (size_t)(NMS_TH + 2 * radius) * NMS_TW) * 4;
+    {
+        typedef void (*launch_fn)(hipStream_t, dim3, size_t, const float *, int, int, int, float, const uint32_t *,
+                                  unsigned long long *, int);
+        static const launch_fn fixed[9] = {launch_nms_tile<0>, launch_nms_tile<1>, launch_nms_tile<2>, launch_nms_tile<3>,
+                                           launch_nms_tile<4>, launch_nms_tile<5>, launch_nms_tile<6>, launch_nms_tile<7>,
+                                           launch_nms_tile<8>};
+        (radius <= 8 ? fixed[radius] : fixed[0])(ctx->stream, grid, nms_lds, d_R, width, height, radius, rel_thresh,
+                                                 (const uint32_t *)d_max, d_cand, tile_slots);
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), 0, ctx->stream, (const unsigned long long *)d_cand, cap,
+                       width, K, d_xy, d_sc, d_cnt);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+static int corners_copy_out(vo_ctx *ctx, int batch, int K, const float *d_xy, const float *d_sc, const int *d_cnt, float *xy,
+                            float *scores, int32_t *count)
+{
+    VO_HIP_CHECK(hipMemcpyAsync(xy, d_xy, (size_t)batch * K * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores) VO_HIP_CHECK(hipMemcpyAsync(scores, d_sc, (size_t)batch * K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(count, d_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
 
@@ -388,11 +468,6 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_nms_topk: bad mem flag %d", mem);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t npix = (size_t)width * height;
-    // survivors are more than `radius` apart, so a 64x16 tile holds at most this many
-    const int tile_slots = ((NMS_TW + radius) / (radius + 1)) * ((NMS_TH + radius) / (radius + 1));
-    dim3 grid((width + NMS_TW - 1) / NMS_TW, (height + NMS_TH - 1) / NMS_TH, batch);
-    VO_REQUIRE(grid.y <= 65535u, "vo_nms_topk: image too tall");
-    const int cap = (int)(grid.x * grid.y) * tile_slots;  // candidate slots per image
     int rc;
     void *p;
     const float *d_R = R;
@@ -405,34 +480,57 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
         if ((rc = vo_stage_reserve(ctx, 4, (size_t)batch * 4, &p))) return rc; d_cnt = (int *)p;
         VO_HIP_CHECK(hipMemcpyAsync((void *)d_R, R, npix * batch * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    if ((rc = vo_stage_reserve(ctx, 5, (size_t)batch * cap * 8, &p))) return rc;
-    unsigned long long *d_cand = (unsigned long long *)p;
-    VO_HIP_CHECK(hipMemsetAsync(d_cand, 0, (size_t)batch * cap * 8, ctx->stream));
-    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * 4, &p))) return rc;
-    uint32_t *d_max = (uint32_t *)p;
-    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * 4, ctx->stream));
-    int mblocks = (int)((npix / 4 + 256 * 4 - 1) / (256 * 4));
-    if (mblocks > 512) mblocks = 512;
-    if (mblocks < 1) mblocks = 1;
-    hipLaunchKernelGGL(max_key_kernel, dim3(mblocks, batch), dim3(256), 0, ctx->stream, d_R, (int64_t)npix, d_max);
-    const size_t nms_lds = ((size_t)(NMS_TH + 2 * radius) * (NMS_TW + 2 * radius) + (size_t)(NMS_TH + 2 * radius) * NMS_TW) * 4;
-    {
-        typedef void (*launch_fn)(hipStream_t, dim3, size_t, const float *, int, int, int, float, const uint32_t *,
-                                  unsigned long long *, int);
-        static const launch_fn fixed[9] = {launch_nms_tile<0>, launch_nms_tile<1>, launch_nms_tile<2>, launch_nms_tile<3>,
-                                           launch_nms_tile<4>, launch_nms_tile<5>, launch_nms_tile<6>, launch_nms_tile<7>,
-                                           launch_nms_tile<8>};
-        (radius <= 8 ? fixed[radius] : fixed[0])(ctx->stream, grid, nms_lds, d_R, width, height, radius, rel_thresh,
-                                                 (const uint32_t *)d_max, d_cand, tile_slots);
-    }
-    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), 0, ctx->stream, (const unsigned long long *)d_cand, cap,
-                       width, K, d_xy, d_sc, d_cnt);
-    VO_HIP_CHECK(hipGetLastError());
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
+    VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
+    if ((rc = nms_select(ctx, d_R, batch, height, width, rel_thresh, radius, K, (uint32_t *)p, false, d_xy, d_sc, d_cnt))) return rc;
+    if (mem == VO_MEM_HOST) return corners_copy_out(ctx, batch, K, d_xy, d_sc, d_cnt, xy, scores, count);
+    return VO_OK;
+}
+
+extern "C" int vo_detect_corners(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
+                                 int64_t img_stride, float k, int mode, float rel_thresh, int radius, int K, float *xy,
+                                 float *scores, int32_t *count, int mem)
+{
+    VO_REQUIRE(ctx && img && xy && count, "vo_detect_corners: NULL argument");
+    VO_REQUIRE(batch >= 1 && batch <= 65535 && height >= 3 && width >= 3, "vo_detect_corners: bad shape batch=%d h=%d w=%d", batch, height, width);
+    VO_REQUIRE((int64_t)height * width < (1ll << 31), "vo_detect_corners: image too large");
+    VO_REQUIRE(mode == 0 || mode == 1, "vo_detect_corners: mode %d (0 = Harris, 1 = min eigenvalue)", mode);
+    VO_REQUIRE(row_stride >= width && (batch == 1 || img_stride >= row_stride * height), "vo_detect_corners: bad strides");
+    VO_REQUIRE(radius >= 1 && radius <= 32, "vo_detect_corners: radius %d out of [1,32]", radius);
+    VO_REQUIRE(K >= 1 && K <= TOPK_MAX, "vo_detect_corners: K=%d out of [1,%d]", K, TOPK_MAX);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_detect_corners: bad mem flag %d", mem);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc;
+    void *p;
+    const size_t npix = (size_t)width * height;
+    const uint8_t *d_img = img;
+    int64_t pitch = row_stride, istride = img_stride;
+    float *d_xy = xy, *d_sc = scores;
+    int *d_cnt = count;
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(xy, d_xy, (size_t)batch * K * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (scores) VO_HIP_CHECK(hipMemcpyAsync(scores, d_sc, (size_t)batch * K * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(count, d_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if ((rc = vo_stage_reserve(ctx, 0, npix * batch, &p))) return rc; d_img = (const uint8_t *)p;
+        if ((rc = vo_stage_reserve(ctx, 2, (size_t)batch * K * 8, &p))) return rc; d_xy = (float *)p;
+        if ((rc = vo_stage_reserve(ctx, 3, (size_t)batch * K * 4, &p))) return rc; d_sc = scores ? (float *)p : nullptr;
+        if ((rc = vo_stage_reserve(ctx, 4, (size_t)batch * 4, &p))) return rc; d_cnt = (int *)p;
+        if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
+            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            for (int b = 0; b < batch; ++b)
+                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
+                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+        }
+        pitch = width; istride = (int64_t)npix;
     }
+    if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc;     // library-owned response map
+    float *d_R = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
+    uint32_t *d_max = (uint32_t *)p;
+    VO_HIP_CHECK(hipMemsetAsync(d_max, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
+    dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);
+    VO_REQUIRE(grid.y <= 65535u, "vo_detect_corners: image too tall");
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
+                       d_max);
+    if ((rc = nms_select(ctx, d_R, batch, height, width, rel_thresh, radius, K, d_max, true, d_xy, d_sc, d_cnt))) return rc;
+    if (mem == VO_MEM_HOST) return corners_copy_out(ctx, batch, K, d_xy, d_sc, d_cnt, xy, scores, count);
     return VO_OK;
 }

@@ -365,6 +365,34 @@ def nms_topk(ctx: Context, R, K: int, rel_thresh: float = 0.01, radius: int = 1)
     return xy, sc, cnt
 
 
+def detect_corners(ctx: Context, imgs, K: int, rel_thresh: float = 0.01, radius: int = 1, k: float = 0.04,
+                   mode: int = MIN_EIGEN):
+    """Corner response + non-maximum suppression + top-K in one call over uint8 images (H,W) or
+    (B,H,W) -> (xy (B,K,2) f32, scores (B,K) f32, count (B,) i32); same results as harris_response
+    followed by nms_topk."""
+    if _is_torch(imgs):
+        import torch
+        t = imgs if imgs.dim() == 3 else imgs.unsqueeze(0)
+        assert t.dtype == torch.uint8 and t.is_cuda
+        if t.stride(2) != 1:
+            t = t.contiguous()
+        B, H, W = t.shape
+        xy = torch.empty((B, K, 2), dtype=torch.float32, device=t.device)
+        sc = torch.empty((B, K), dtype=torch.float32, device=t.device)
+        cnt = torch.empty(B, dtype=torch.int32, device=t.device)
+        rs, ist, mem = t.stride(1), (t.stride(0) if B > 1 else t.stride(1) * H), VO_MEM_DEVICE
+    else:
+        t = np.ascontiguousarray(imgs, dtype=np.uint8)
+        if t.ndim == 2:
+            t = t[None]
+        B, H, W = t.shape
+        xy = np.zeros((B, K, 2), np.float32); sc = np.zeros((B, K), np.float32); cnt = np.zeros(B, np.int32)
+        rs, ist, mem = t.strides[1], t.strides[0], VO_MEM_HOST
+    check(ctx.lib.vo_detect_corners(ctx.handle, _ptr(t), B, H, W, rs, ist, float(k), int(mode), float(rel_thresh),
+                                    int(radius), int(K), _ptr(xy), _ptr(sc), _ptr(cnt), mem), "vo_detect_corners")
+    return xy, sc, cnt
+
+
 def p3p_solve(ctx: Context, X, x, K, subsets):
     """P3P per 4-point sample -> (Rt (S,3,4) f64, valid (S,) u8).  subsets: (S,4) int32."""
     Kh = _k_host(K)

@@ -30,9 +30,8 @@ class FeatureExtractor:
                 k: float = 0.04, shi_tomasi: bool = True) -> np.ndarray:
         """Strongest `max_corners` local maxima of the Shi-Tomasi (or Harris) response, (M,2) float32 (x,y)."""
         ctx = _runtime.context()
-        R = hip.harris_response(ctx, np.ascontiguousarray(img, dtype=np.uint8), k,
-                                hip.MIN_EIGEN if shi_tomasi else hip.HARRIS)
-        xy, _, cnt = hip.nms_topk(ctx, R, int(max_corners), float(quality), int(radius))
+        xy, _, cnt = hip.detect_corners(ctx, np.ascontiguousarray(img, dtype=np.uint8), int(max_corners), float(quality),
+                                        int(radius), k, hip.MIN_EIGEN if shi_tomasi else hip.HARRIS)
         return xy[0, :int(cnt[0])]
 
     @staticmethod
@@ -46,6 +45,5 @@ class FeatureExtractor:
         positions of the 3x3 local maxima above the same threshold, strongest first
         (at most 4096)."""
         ctx = _runtime.context()
-        R = hip.harris_response(ctx, np.ascontiguousarray(img, dtype=np.uint8), 0.1, hip.HARRIS)
-        xy, _, cnt = hip.nms_topk(ctx, R, 4096, 0.01, 1)
+        xy, _, cnt = hip.detect_corners(ctx, np.ascontiguousarray(img, dtype=np.uint8), 4096, 0.01, 1, 0.1, hip.HARRIS)
         return xy[0, :int(cnt[0])]
