@@ -183,33 +183,63 @@ __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ 
 
 #define NMS_TW 64
 #define NMS_TH 16
+#define NMS_MAX_SLOTS 256      // survivors of one tile at the smallest radius: (65 / 2) * (17 / 2)
+#define TOPK_POOL 8192         // candidate keys topk_kernel keeps in LDS
 
 // Window non-maximum suppression in one pass over R.  A workgroup stages a 64x16
 // tile with a halo of `radius` pixels (outside the image: -inf) and takes the running
 // maximum along rows, then along columns, the rows above the centre separately.  A
 // pixel above the threshold survives when it equals its window maximum and every
 // earlier raster neighbour (rows above, left part of its own row) is strictly
-// smaller: an earlier neighbour wins ties.  Survivors leave as 64-bit keys
-// {ordered(R), ~raster index} in the tile's own slots of the candidate array
-// (survivors are more than `radius` apart, which bounds their number per tile; zero
-// marks an empty slot).  RAD > 0 fixes the
-// radius at compile time (fully unrolled window loops); RAD == 0 takes it at run time.
+// smaller: an earlier neighbour wins ties.  Survivors are more than `radius` apart,
+// which bounds their number per tile; they are collected in LDS as 64-bit keys
+// {ordered(R), ~raster index} and stored in the tile's own slots of the candidate
+// array, the unused slots zeroed (zero marks an empty slot): no global atomic and no
+// clearing of the array between calls.
+// RAD > 0 fixes the radius at compile time: a lane then finishes four neighbouring
+// outputs per step from one set of 16-byte LDS reads (row pass) or one column of
+// row maxima held in registers (column pass).  RAD == 0 takes the radius at run time.
 template <int RAD>
 __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__ R, int w, int h, int radius, float rel_thresh,
                                                        const uint32_t *__restrict__ maxkey,
                                                        unsigned long long *__restrict__ cand, int tile_slots)
 {
-    extern __shared__ float nms_lds[];
+    extern __shared__ __attribute__((aligned(16))) float nms_lds[];
+    __shared__ unsigned long long s_keys[NMS_MAX_SLOTS];
     __shared__ int s_n;
-    const int r = RAD > 0 ? RAD : radius, TW = NMS_TW + 2 * r, TH = NMS_TH + 2 * r;
+    const int r = RAD > 0 ? RAD : radius, TH = NMS_TH + 2 * r;
+    // row stride: whole 16-byte groups, wide enough for the last lane's reads of the row pass
+    const int TW = RAD > 0 ? NMS_TW - 4 + 4 * ((4 + 2 * r + 3) / 4) : NMS_TW + 2 * r;
     float *tile = nms_lds, *hm = nms_lds + TH * TW;
     const int b = blockIdx.z, x0 = blockIdx.x * NMS_TW, y0 = blockIdx.y * NMS_TH;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const float *src = R + (int64_t)b * w * h;
     const float ninf = -__builtin_inff();
     if (threadIdx.x == 0) s_n = 0;
-    // sixteen independent reads in flight per lane (eight rows x two column groups):
-    // one round for radius <= 8
+    const uint32_t image_max = maxkey[b * MAXKEY_STRIDE];   // issued with the tile reads, needed after them
+    const bool interior = RAD > 0 && x0 - r >= 0 && x0 - r + TW <= w && y0 - r >= 0 && y0 - r + TH <= h;
+    if (interior) {
+        // whole tile inside the image: 16-byte reads (4-byte aligned in memory, 16-byte aligned in LDS),
+        // all of a lane's reads in flight before the first LDS store
+        constexpr int RADC = RAD > 0 ? RAD : 1;
+        constexpr int TWC = NMS_TW - 4 + 4 * ((4 + 2 * RADC + 3) / 4), V4 = TWC / 4;
+        constexpr int ITEMS = (NMS_TH + 2 * RADC) * V4, ROUNDS = (ITEMS + 255) / 256;
+        const float *base = src + (int64_t)(y0 - r) * w + (x0 - r);
+        float4 v[ROUNDS];
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int idx = min((int)threadIdx.x + 256 * q, ITEMS - 1);
+            const int row = idx / V4, c4 = idx - row * V4;
+            __builtin_memcpy(&v[q], base + (int64_t)row * w + 4 * c4, 16);
+        }
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int idx = min((int)threadIdx.x + 256 * q, ITEMS - 1);
+            *reinterpret_cast<float4 *>(tile + 4 * idx) = v[q];
+        }
+    } else
+    // tiles on the image border: sixteen independent reads in flight per lane (eight rows x two
+    // column groups), one round for radius <= 8
     for (int yb = ly; yb < TH; yb += 32) {
         float v[8][2];
 #pragma unroll
@@ -233,26 +263,74 @@ __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__
         }
     }
     __syncthreads();
-    for (int yy = ly; yy < TH; yy += 4) {
-        const float *t = tile + yy * TW + lx;
-        float m = t[0];
-        for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, t[d]);
-        hm[yy * NMS_TW + lx] = m;
+    if (RAD > 0) {
+        constexpr int NV = (4 + 2 * RAD + 3) / 4;       // 16-byte reads covering the 4 + 2r inputs of four outputs
+        const int q4 = (threadIdx.x & 15) * 4;
+        for (int yy = threadIdx.x >> 4; yy < TH; yy += 16) {
+            float in[4 * NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const float4 f = *reinterpret_cast<const float4 *>(tile + yy * TW + q4 + 4 * k);
+                in[4 * k] = f.x; in[4 * k + 1] = f.y; in[4 * k + 2] = f.z; in[4 * k + 3] = f.w;
+            }
+            float4 o;
+            if constexpr (RAD >= 2) {
+                // inputs 3 .. 2r are common to the four windows
+                float core = in[3];
+#pragma unroll
+                for (int d = 4; d <= 2 * RAD; ++d) core = fmaxf(core, in[d]);
+                o.x = fmaxf(fmaxf(core, in[2]), fmaxf(in[1], in[0]));
+                o.y = fmaxf(fmaxf(core, in[2]), fmaxf(in[1], in[2 * RAD + 1]));
+                o.z = fmaxf(fmaxf(core, in[2]), fmaxf(in[2 * RAD + 2], in[2 * RAD + 1]));
+                o.w = fmaxf(fmaxf(core, in[2 * RAD + 3]), fmaxf(in[2 * RAD + 2], in[2 * RAD + 1]));
+            } else {
+                o.x = fmaxf(fmaxf(in[0], in[1]), in[2]);
+                o.y = fmaxf(fmaxf(in[1], in[2]), in[3]);
+                o.z = fmaxf(fmaxf(in[2], in[3]), in[4]);
+                o.w = fmaxf(fmaxf(in[3], in[4]), in[5]);
+            }
+            *reinterpret_cast<float4 *>(hm + yy * NMS_TW + q4) = o;
+        }
+    } else {
+        for (int yy = ly; yy < TH; yy += 4) {
+            const float *t = tile + yy * TW + lx;
+            float m = t[0];
+            for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, t[d]);
+            hm[yy * NMS_TW + lx] = m;
+        }
     }
     __syncthreads();
-    const float thr = rel_thresh * key_value(maxkey[b * MAXKEY_STRIDE]);
+    const float thr = rel_thresh * key_value(image_max);
     const int py0 = ly * 4;  // this lane finishes tile rows py0..py0+3 of column lx
     const float *hc = hm + lx;
+    float above[4], rest[4];
+    if (RAD > 0) {
+        float col[4 + 2 * (RAD > 0 ? RAD : 1)];   // row maxima of window rows py0 .. py0+3+2r
+#pragma unroll
+        for (int d = 0; d < 4 + 2 * RAD; ++d) col[d] = hc[(py0 + d) * NMS_TW];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            above[j] = ninf; rest[j] = ninf;
+#pragma unroll
+            for (int d = 0; d < RAD; ++d) above[j] = fmaxf(above[j], col[j + d]);
+#pragma unroll
+            for (int d = RAD; d <= 2 * RAD; ++d) rest[j] = fmaxf(rest[j], col[j + d]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *hj = hc + (py0 + j) * NMS_TW;
+            above[j] = ninf; rest[j] = ninf;
+            for (int d = 0; d < r; ++d) above[j] = fmaxf(above[j], hj[d * NMS_TW]);
+            for (int d = r; d <= 2 * r; ++d) rest[j] = fmaxf(rest[j], hj[d * NMS_TW]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float *hj = hc + (py0 + j) * NMS_TW;  // window rows py0+j .. py0+j+2r of the row maxima
-        float above = ninf, rest = ninf;
-        for (int d = 0; d < r; ++d) above = fmaxf(above, hj[d * NMS_TW]);
-        for (int d = r; d <= 2 * r; ++d) rest = fmaxf(rest, hj[d * NMS_TW]);
         const int gx = x0 + lx, gy = y0 + py0 + j;
         const float *c = tile + (py0 + j + r) * TW + lx + r;
         const float v = c[0];
-        bool ok = gx < w && gy < h && v > thr && v >= rest && v > above;
+        bool ok = gx < w && gy < h && v > thr && v >= rest[j] && v > above[j];
         if (ok) {
             float left = ninf;
             for (int d = 1; d <= r; ++d) left = fmaxf(left, c[-d]);
@@ -261,16 +339,15 @@ __global__ __launch_bounds__(256) void nms_tile_kernel(const float *__restrict__
         if (ok) {
             const uint32_t idx = (uint32_t)(gy * w + gx);
             const int slot = atomicAdd(&s_n, 1);
-            const int64_t tile_id = ((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            if (slot < tile_slots)
-                cand[tile_id * tile_slots + slot] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
+            if (slot < NMS_MAX_SLOTS) s_keys[slot] = ((unsigned long long)ordered_key(v) << 32) | (0xffffffffu - idx);
         }
     }
     __syncthreads();
     {
-        // the tile's unused slots are marked empty here, so the candidate array needs no clearing
+        const int n = min(s_n, NMS_MAX_SLOTS);
         const int64_t tile_id = ((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        for (int slot = s_n + threadIdx.x; slot < tile_slots; slot += 256) cand[tile_id * tile_slots + slot] = 0ull;
+        for (int slot = threadIdx.x; slot < tile_slots; slot += 256)
+            cand[tile_id * tile_slots + slot] = slot < n ? s_keys[slot] : 0ull;
     }
 }
 
@@ -281,60 +358,52 @@ static void launch_nms_tile(hipStream_t stream, dim3 grid, size_t lds, const flo
     hipLaunchKernelGGL(nms_tile_kernel<RAD>, grid, dim3(256), lds, stream, R, w, h, radius, rel_thresh, maxkey, cand, tile_slots);
 }
 
-__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long long *__restrict__ cand, int cap, int w, int K,
-                                                            float *__restrict__ xy, float *__restrict__ scores,
-                                                            int *__restrict__ count)
+// Top-K of an image's candidate keys, strongest first.  One workgroup per image: the filled slots are
+// collected in LDS when they fit (TOPK_POOL keys; otherwise every pass re-reads the slots from memory), the
+// K-th largest key is found by radix selection (8 x 8-bit passes), the winners are gathered and
+// bitonic-sorted.  Keys are unique, so the result does not depend on the order of the list.
+template <bool POOLED>
+__device__ __forceinline__ void topk_body(const unsigned long long *__restrict__ c, const unsigned long long *pool, int n,
+                                          int valid, int w,
+                                          int K, unsigned long long *sel, int *hist, unsigned long long *s_prefix, int *s_need,
+                                          int *s_nsel, float *__restrict__ xy, float *__restrict__ scores,
+                                          int *__restrict__ count, int b)
 {
-    __shared__ unsigned long long sel[TOPK_MAX];
-    __shared__ int hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_need, s_nsel;
-    const int b = blockIdx.x, t = threadIdx.x;
-    const unsigned long long *c = cand + (int64_t)b * cap;
-    const int n = cap;  // slots; a zero key is an empty slot
-    if (t == 0) s_nsel = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int i = t; i < n; i += TOPK_THREADS) mine += c[i] != 0ull;
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((t & 63) == 0 && mine) atomicAdd(&s_nsel, mine);
-    __syncthreads();
-    const int valid = s_nsel;
-    __syncthreads();
+    const int t = threadIdx.x;
     const int m = min(valid, K);
     unsigned long long T = 1;  // K-th largest key (everything >= T is selected); 1 = every filled slot
     if (valid > K) {
-        if (t == 0) { s_prefix = 0; s_need = K; }
+        if (t == 0) { *s_prefix = 0; *s_need = K; }
         for (int shift = 56; shift >= 0; shift -= 8) {
             if (t < 256) hist[t] = 0;
             __syncthreads();
-            const unsigned long long prefix = s_prefix;
+            const unsigned long long prefix = *s_prefix;
             const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
             for (int i = t; i < n; i += TOPK_THREADS) {
-                const unsigned long long key = c[i];
-                if (key != 0ull && (key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+                const unsigned long long key = POOLED ? pool[i] : c[i];
+                if ((POOLED || key != 0ull) && (key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
             }
             __syncthreads();
             if (t == 0) {
-                int need = s_need, bin = 255;
+                int need = *s_need, bin = 255;
                 for (; bin > 0; --bin) {
                     if (hist[bin] >= need) break;
                     need -= hist[bin];
                 }
-                s_need = need;
-                s_prefix = prefix | ((unsigned long long)bin << shift);
+                *s_need = need;
+                *s_prefix = prefix | ((unsigned long long)bin << shift);
             }
             __syncthreads();
         }
-        T = s_prefix;
+        T = *s_prefix;
     }
-    if (t == 0) s_nsel = 0;
+    if (t == 0) *s_nsel = 0;
     for (int i = t; i < TOPK_MAX; i += TOPK_THREADS) sel[i] = 0;
     __syncthreads();
     for (int i = t; i < n; i += TOPK_THREADS) {
-        const unsigned long long key = c[i];
+        const unsigned long long key = POOLED ? pool[i] : c[i];
         if (key >= T) {
-            const int pos = atomicAdd(&s_nsel, 1);
+            const int pos = atomicAdd(s_nsel, 1);
             if (pos < TOPK_MAX) sel[pos] = key;
         }
     }
@@ -369,6 +438,42 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long 
     if (t == 0) count[b] = m;
 }
 
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long long *__restrict__ cand, int cap, int w, int K,
+                                                            float *__restrict__ xy, float *__restrict__ scores,
+                                                            int *__restrict__ count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pool[];   // TOPK_POOL keys
+    __shared__ unsigned long long sel[TOPK_MAX];
+    __shared__ int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_need, s_nsel;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const unsigned long long *c = cand + (int64_t)b * cap;
+    if (t == 0) s_nsel = 0;
+    __syncthreads();
+    // one pass over the slots: filled ones go to the pool (in no particular order) and are counted
+    for (int i0 = 0; i0 < cap; i0 += 4 * TOPK_THREADS) {
+        unsigned long long k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * TOPK_THREADS + t;
+            k4[u] = i < cap ? c[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k4[u] != 0ull) {
+                const int pos = atomicAdd(&s_nsel, 1);
+                if (pos < TOPK_POOL) pool[pos] = k4[u];
+            }
+    }
+    __syncthreads();
+    const int valid = s_nsel;
+    __syncthreads();
+    if (valid <= TOPK_POOL)
+        topk_body<true>(c, pool, valid, valid, w, K, sel, hist, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
+    else
+        topk_body<false>(c, pool, cap, valid, w, K, sel, hist, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
+}
 
 extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
                                   int64_t img_stride, int block_size, int ksize, float k, int mode, float *R, int mem)
@@ -431,7 +536,8 @@ static int nms_select(vo_ctx *ctx, const float *d_R, int batch, int height, int 
         if (mblocks < 1) mblocks = 1;
         hipLaunchKernelGGL(max_key_kernel, dim3(mblocks, batch), dim3(256), 0, ctx->stream, d_R, (int64_t)npix, d_max);
     }
-    const size_t nms_lds = ((size_t)(NMS_TH + 2 * radius) * (NMS_TW + 2 * radius) + (size_t)(NMS_TH + 2 * radius) * NMS_TW) * 4;
+    const int tile_w = radius <= 8 ? NMS_TW - 4 + 4 * ((4 + 2 * radius + 3) / 4) : NMS_TW + 2 * radius;   // as in the kernel
+    const size_t nms_lds = ((size_t)(NMS_TH + 2 * radius) * tile_w + (size_t)(NMS_TH + 2 * radius) * NMS_TW) * 4;
     {
         typedef void (*launch_fn)(hipStream_t, dim3, size_t, const float *, int, int, int, float, const uint32_t *,
                                   unsigned long long *, int);
@@ -441,8 +547,13 @@ static int nms_select(vo_ctx *ctx, const float *d_R, int batch, int height, int 
         (radius <= 8 ? fixed[radius] : fixed[0])(ctx->stream, grid, nms_lds, d_R, width, height, radius, rel_thresh,
                                                  (const uint32_t *)d_max, d_cand, tile_slots);
     }
-    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), 0, ctx->stream, (const unsigned long long *)d_cand, cap,
-                       width, K, d_xy, d_sc, d_cnt);
+    static bool pool_enabled[64] = {false};   // per device: the kernel's dynamic LDS exceeds the default per-launch limit
+    if (ctx->device < 0 || ctx->device >= 64 || !pool_enabled[ctx->device]) {
+        VO_HIP_CHECK(hipFuncSetAttribute((const void *)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TOPK_POOL * 8));
+        if (ctx->device >= 0 && ctx->device < 64) pool_enabled[ctx->device] = true;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TOPK_THREADS), TOPK_POOL * 8, ctx->stream,
+                       (const unsigned long long *)d_cand, cap, width, K, d_xy, d_sc, d_cnt);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
