@@ -6,26 +6,12 @@
 // size ((w+1)/2, (h+1)/2), and a level count clamped so that every level stays
 // larger than the tracking window.
 //
-// HBM-bound byte work: one workgroup turns a (2*64+3) x (2*16+3) input tile,
-// staged once in LDS, into a 64 x 16 output tile; rows are filtered horizontally
-// into 16-bit sums in LDS, then vertically, and each thread stores four output
-// pixels as one aligned dword (level pitches are multiples of 64 bytes).
+// HBM-bound byte work with no reuse beyond a 5x5 stencil: the kernel keeps nothing in LDS;
+// every lane streams the input rows of its four output columns through registers (see
+// pyr_down_rows_kernel).  Level pitches are multiples of 64 bytes, so a lane's four output
+// pixels leave as one aligned dword.
 #include "vo_internal.h"
 #include <new>
-
-#define PD_TW 64          // output tile width
-#define PD_TH 16          // output tile height
-#define PD_IW (2 * PD_TW + 3)
-#define PD_IH (2 * PD_TH + 3)
-#define PD_IS 132         // LDS row stride of the input tile (bytes)
-
-__device__ __forceinline__ int reflect101(int i, int n)
-{
-    // valid for -n < i < 2n-1, which the window/halo sizes used here guarantee
-    i = i < 0 ? -i : i;
-    i = i >= n ? 2 * n - 2 - i : i;
-    return i;
-}
 
 typedef unsigned short pd_u16x2 __attribute__((ext_vector_type(2)));
 
@@ -34,130 +20,123 @@ __device__ __forceinline__ pd_u16x2 pd_pair(uint32_t hi, uint32_t lo, uint32_t s
     return __builtin_bit_cast(pd_u16x2, __builtin_amdgcn_perm(hi, lo, sel));
 }
 
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int sw, int sh,
-                                                       int64_t spitch, int64_t sstride,
-                                                       uint8_t *__restrict__ dst, int dw, int dh,
-                                                       int64_t dpitch, int64_t dstride, int tiles_x, int tiles_y, int batch)
+// No LDS, no barrier.  A lane owns four neighbouring output columns and
+// PR_RO consecutive output rows (8 for large levels, 4 where that is needed to fill the chip); it issues the reads of all 2*PR_RO+3 input rows it needs (three
+// unaligned dwords = 12 bytes per row) before the first use, so a wavefront keeps ~14 KB in flight,
+// filters each row horizontally with packed 16-bit math (the bytes b0..b11 of a row become 16-bit lane
+// pairs {b0,b2} {b1,b3} ... through v_perm_b32, so one packed instruction yields two neighbouring
+// outputs; 255 * 16 * 16 + 128 < 65536) and runs the vertical
+// filter over a rolling window of five filtered rows held in registers.  Consecutive lanes take
+// consecutive column groups (a row of 4-byte stores per wavefront and output row).  Rows are
+// reflected (REFLECT_101) by address; lanes whose 12-byte window would leave the row read the 12
+// bytes that end at (or start at) the row border instead and gather their window from them with
+// per-lane byte selectors; wavefronts without such a lane skip the gather.
+
+__device__ __forceinline__ void pr_hrow(uint32_t n0, uint32_t n1, uint32_t n2, pd_u16x2 &h01, pd_u16x2 &h23)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[PD_IH * PD_IS];
-    __shared__ __attribute__((aligned(16))) uint16_t hsum[PD_IH * PD_TW];
+    const pd_u16x2 a0 = pd_pair(n1, n0, 0x0c020c00u), a1 = pd_pair(n1, n0, 0x0c030c01u), a2 = pd_pair(n1, n0, 0x0c040c02u),
+                   a3 = pd_pair(n1, n0, 0x0c050c03u), a4 = pd_pair(n1, n0, 0x0c060c04u);
+    const pd_u16x2 b1 = pd_pair(n2, n1, 0x0c030c01u), b2 = pd_pair(n2, n1, 0x0c040c02u),
+                   b3 = pd_pair(n2, n1, 0x0c050c03u), b4 = pd_pair(n2, n1, 0x0c060c04u);
+    h01 = (a0 + a4) + (a1 + a3) * (unsigned short)4 + a2 * (unsigned short)6;
+    h23 = (a4 + b4) + (b1 + b3) * (unsigned short)4 + b2 * (unsigned short)6;   // a4 = {b4, b6} is the pair's first tap
+}
 
-    const int t = threadIdx.x;
-    // workgroups b and b+8 run on the same XCD (round-robin dispatch): give every XCD whole
-    // images, so the rows two neighbouring tiles share are fetched into one L2 only
-    const int per_image = tiles_x * tiles_y;
-    int bid = blockIdx.x, img, tl;
-    if ((batch & 7) == 0) {
+template <int PR_RO>
+__global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__restrict__ src, int sw, int sh, int64_t spitch,
+                                                            int64_t sstride, uint8_t *__restrict__ dst, int dw, int dh,
+                                                            int64_t dpitch, int64_t dstride, int groups, int strips,
+                                                            int wgs_per_image, int batch)
+{
+    constexpr int PR_ROWS = 2 * PR_RO + 3;
+    int bid = blockIdx.x, img, wg;
+    if ((batch & 7) == 0) {     // workgroups b and b+8 share an XCD: whole images per XCD
         const int xcd = bid & 7, j = bid >> 3;
-        img = (j / per_image) * 8 + xcd;
-        tl = j % per_image;
+        img = (j / wgs_per_image) * 8 + xcd;
+        wg = j % wgs_per_image;
     } else {
-        img = bid / per_image;
-        tl = bid % per_image;
+        img = bid / wgs_per_image;
+        wg = bid % wgs_per_image;
     }
-    const int ox0 = (tl % tiles_x) * PD_TW, oy0 = (tl / tiles_x) * PD_TH;
-    const uint8_t *simg = src + (int64_t)img * sstride;
-    uint8_t *dimg = dst + (int64_t)img * dstride;
-    const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2;
+    const int tid = wg * 256 + threadIdx.x;
+    if (tid >= groups * strips) return;
+    const int strip = tid / groups, g = tid - strip * groups;
+    const int ox = 4 * g, oy0 = strip * PR_RO;
+    const int cx = 2 * ox - 2;                          // first input column of the lane's window
+    const bool inrow = cx >= 0 && cx + 12 <= sw;
+    const int colbase = min(max(cx, 0), sw - 12);       // the launch requires sw >= 12
+    const uint8_t *simg = src + (int64_t)img * sstride + colbase;
 
-    // stage the input tile.  Interior tiles: unaligned 4-byte reads, consecutive lanes
-    // on consecutive dwords of a row (33 dwords cover the 131 bytes needed), all five
-    // reads of a lane in flight before the first LDS store; tiles touching the image
-    // border read bytes with REFLECT_101 applied.
-    const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + 4 * (PD_IS / 4) <= sw && iy0 + PD_IH <= sh;
-    if (interior) {
-        const uint8_t *base = simg + (int64_t)iy0 * spitch + ix0;
-        uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
-        constexpr int ITEMS = PD_IH * (PD_IS / 4), ROUNDS = (ITEMS + 255) / 256;
-        uint32_t q[ROUNDS];
+    uint32_t w[PR_ROWS][3];
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int idx = min(t + 256 * k, ITEMS - 1);
-            const int r = (idx * 1986) >> 16, c = idx - r * (PD_IS / 4);   // idx / 33 for idx < 2560
-            __builtin_memcpy(&q[k], base + (int64_t)r * spitch + 4 * c, 4);
-        }
+    for (int k = 0; k < PR_ROWS; ++k) {
+        int y = 2 * oy0 - 2 + k;
+        y = y < 0 ? -y : y;
+        y = y >= sh ? 2 * sh - 2 - y : y;
+        y = min(max(y, 0), sh - 1);                      // rows needed only by outputs below the image
+        const uint8_t *row = simg + (int64_t)y * spitch;
+        __builtin_memcpy(&w[k][0], row, 4);
+        __builtin_memcpy(&w[k][1], row + 4, 4);
+        __builtin_memcpy(&w[k][2], row + 8, 4);
+    }
+
+    const bool gather = __ballot(!inrow) != 0;           // wave-uniform
+    uint32_t selA[3] = {0x03020100u, 0x07060504u, 0u}, selB[3] = {0x03020100u, 0x03020100u, 0x07060504u};
+    if (gather) {
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) tile32[min(t + 256 * k, ITEMS - 1)] = q[k];
-    } else {
-        // tiles touching the image border: same dword items with the row reflected per item;
-        // only the dwords that straddle the left/right border fall back to four byte reads
-        // with REFLECT_101.  Positions needed only by outputs outside the image may fall
-        // outside the reflect range; they are clamped (their results are never stored).
-        uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
-        constexpr int ITEMS = PD_IH * (PD_IS / 4), ROUNDS = (ITEMS + 255) / 256;
-        uint32_t q[ROUNDS];
+        for (int j = 0; j < 3; ++j) {
+            uint32_t sa = 0, sb = 0;
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int idx = min(t + 256 * k, ITEMS - 1);
-            const int r = (idx * 1986) >> 16, c = idx - r * (PD_IS / 4);
-            int y = min(max(iy0 + r, -(sh - 1)), 2 * sh - 2);
-            y = sh > 1 ? reflect101(y, sh) : 0;
-            const uint8_t *row = simg + (int64_t)y * spitch;
-            const int x = ix0 + 4 * c;
-            if (x >= 0 && x + 3 < sw) {
-                __builtin_memcpy(&q[k], row + x, 4);
-            } else {
-                uint32_t v = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    int xx = min(max(x + b, -(sw - 1)), 2 * sw - 2);
-                    xx = sw > 1 ? reflect101(xx, sw) : 0;
-                    v |= (uint32_t)row[xx] << (8 * b);
-                }
-                q[k] = v;
+            for (int b = 0; b < 4; ++b) {
+                int col = cx + 4 * j + b;
+                col = col < 0 ? -col : col;
+                col = col >= sw ? 2 * sw - 2 - col : col;
+                col = min(max(col, 0), sw - 1);
+                const int pos = min(max(col - colbase, 0), 11);      // byte of the 12 that were read
+                sa |= (uint32_t)(pos < 8 ? pos : 0) << (8 * b);       // from {w1, w0}
+                sb |= (uint32_t)(pos < 8 ? b : pos - 4) << (8 * b);   // keep that byte, or take w2's byte pos - 8
             }
-        }
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) tile32[min(t + 256 * k, ITEMS - 1)] = q[k];
-    }
-    __syncthreads();
-
-    // horizontal 5-tap on every staged row, two adjacent outputs per item: the eight bytes
-    // b0..b7 at the pair's origin become 16-bit lane pairs {b0,b2} {b1,b3} {b2,b4} {b3,b5}
-    // {b4,b6}, so packed 16-bit math yields {h(ox), h(ox+1)} for one dword store
-    {
-        const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(tile);
-        uint32_t *hsum32 = reinterpret_cast<uint32_t *>(hsum);
-        for (int idx = t; idx < PD_IH * (PD_TW / 2); idx += 256) {
-            const int r = idx >> 5, pr = idx & 31;
-            const uint32_t lo = tile32[r * (PD_IS / 4) + pr], hi = tile32[r * (PD_IS / 4) + pr + 1];
-            const pd_u16x2 p0 = pd_pair(hi, lo, 0x0c020c00u), p1 = pd_pair(hi, lo, 0x0c030c01u),
-                           p2 = pd_pair(hi, lo, 0x0c040c02u), p3 = pd_pair(hi, lo, 0x0c050c03u),
-                           p4 = pd_pair(hi, lo, 0x0c060c04u);
-            const pd_u16x2 h = (p0 + p4) + (p1 + p3) * (unsigned short)4 + p2 * (unsigned short)6;
-            hsum32[idx] = __builtin_bit_cast(uint32_t, h);
+            selA[j] = sa; selB[j] = sb;
         }
     }
-    __syncthreads();
 
-    // vertical 5-tap; thread -> 4 consecutive outputs of one row, packed 16-bit math
-    // (255 * 16 * 16 + 128 < 65536)
-    const int oxg = (t & 15) * 4, gx = ox0 + oxg;
+    pd_u16x2 h[5][2];
+    uint8_t *dimg = dst + (int64_t)img * dstride + ox;
 #pragma unroll
-    for (int half = 0; half < PD_TH / 16; ++half) {
-        const int oy = (t >> 4) + 16 * half, gy = oy0 + oy;
-        if (gy < dh && gx < dw) {
-            const uint2 *h0 = reinterpret_cast<const uint2 *>(hsum + (2 * oy) * PD_TW + oxg);
-            constexpr int RS = PD_TW / 4;  // row stride in uint2
-            const uint2 a0 = h0[0], a1 = h0[RS], a2 = h0[2 * RS], a3 = h0[3 * RS], a4 = h0[4 * RS];
+    for (int k = 0; k < PR_ROWS; ++k) {
+        uint32_t n0 = w[k][0], n1 = w[k][1], n2 = w[k][2];
+        if (gather) {
+            const uint32_t t0 = __builtin_amdgcn_perm(n1, n0, selA[0]), t1 = __builtin_amdgcn_perm(n1, n0, selA[1]),
+                           t2 = __builtin_amdgcn_perm(n1, n0, selA[2]);
+            n0 = __builtin_amdgcn_perm(n2, t0, selB[0]);
+            n1 = __builtin_amdgcn_perm(n2, t1, selB[1]);
+            const uint32_t m2 = __builtin_amdgcn_perm(n2, t2, selB[2]);
+            n2 = m2;
+        }
+        pr_hrow(n0, n1, n2, h[k % 5][0], h[k % 5][1]);
+        if (k >= 4 && (k & 1) == 0) {
+            const int o = (k - 4) / 2, gy = oy0 + o;     // rows k-4 .. k are the five taps
             uint32_t out2[2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const pd_u16x2 v0 = __builtin_bit_cast(pd_u16x2, k ? a0.y : a0.x), v1 = __builtin_bit_cast(pd_u16x2, k ? a1.y : a1.x),
-                               v2 = __builtin_bit_cast(pd_u16x2, k ? a2.y : a2.x), v3 = __builtin_bit_cast(pd_u16x2, k ? a3.y : a3.x),
-                               v4 = __builtin_bit_cast(pd_u16x2, k ? a4.y : a4.x);
+            for (int q = 0; q < 2; ++q) {
+                const pd_u16x2 v0 = h[(k - 4) % 5][q], v1 = h[(k - 3) % 5][q], v2 = h[(k - 2) % 5][q], v3 = h[(k - 1) % 5][q],
+                               v4 = h[k % 5][q];
                 const pd_u16x2 v = ((v0 + v4) + (v1 + v3) * (unsigned short)4 + v2 * (unsigned short)6 + (unsigned short)128) >> (unsigned short)8;
-                out2[k] = __builtin_bit_cast(uint32_t, v);
+                out2[q] = __builtin_bit_cast(uint32_t, v);
             }
             // bytes past dw land in the row's pitch padding
-            *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch + gx) = __builtin_amdgcn_perm(out2[1], out2[0], 0x06040200u);
+            if (gy < dh)
+                *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch) = __builtin_amdgcn_perm(out2[1], out2[0], 0x06040200u);
         }
     }
 }
 
+#define PR_TALL_MIN_LANES (1024 * 64 * 2)   // 1024 SIMDs x 64 lanes x 2 wavefronts
+
 static int eff_max_level(int w, int h, int max_level, int win)
 {
     for (int level = 0; level <= max_level; ++level) {
+        if (w < 12) return level;   // the kernel reads 12-byte windows of a source row
         w = (w + 1) / 2;
         h = (h + 1) / 2;
         if (w <= win || h <= win) return level;
@@ -263,12 +242,21 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
         pyr->img_stride[0] = img_stride;
     }
     for (int l = 1; l <= pyr->max_level; ++l) {
-        const int tiles_x = (pyr->w[l] + PD_TW - 1) / PD_TW, tiles_y = (pyr->h[l] + PD_TH - 1) / PD_TH;
-        const int64_t blocks = (int64_t)tiles_x * tiles_y * pyr->batch;
-        VO_REQUIRE(blocks <= 0x7fffffff, "vo_pyr_build: %lld tiles exceed the grid limit", (long long)blocks);
-        hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pyr->lvl[l - 1], pyr->w[l - 1],
-                           pyr->h[l - 1], pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l], pyr->h[l],
-                           pyr->pitch[l], pyr->img_stride[l], tiles_x, tiles_y, pyr->batch);
+        const int groups = (pyr->w[l] + 3) / 4;
+        // eight output rows per lane unless that leaves fewer than ~2 wavefronts per SIMD
+        const bool tall = (int64_t)groups * ((pyr->h[l] + 7) / 8) * pyr->batch >= PR_TALL_MIN_LANES;
+        const int ro = tall ? 8 : 4, strips = (pyr->h[l] + ro - 1) / ro;
+        const int wgs = (groups * strips + 255) / 256;
+        const int64_t blocks = (int64_t)wgs * pyr->batch;
+        VO_REQUIRE(blocks <= 0x7fffffff, "vo_pyr_build: %lld workgroups exceed the grid limit", (long long)blocks);
+        if (tall)
+            hipLaunchKernelGGL(pyr_down_rows_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pyr->lvl[l - 1],
+                               pyr->w[l - 1], pyr->h[l - 1], pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l],
+                               pyr->h[l], pyr->pitch[l], pyr->img_stride[l], groups, strips, wgs, pyr->batch);
+        else
+            hipLaunchKernelGGL(pyr_down_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pyr->lvl[l - 1],
+                               pyr->w[l - 1], pyr->h[l - 1], pyr->pitch[l - 1], pyr->img_stride[l - 1], pyr->lvl[l], pyr->w[l],
+                               pyr->h[l], pyr->pitch[l], pyr->img_stride[l], groups, strips, wgs, pyr->batch);
     }
     VO_HIP_CHECK(hipGetLastError());
     pyr->built = true;
