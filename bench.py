@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=64)
     ap.add_argument("--ring", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="build each frame's pyramid on the tracker's stream, right before it is tracked")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal aid: every rank uses GPU 0 (one-GPU box); never used for reported numbers")
@@ -142,24 +144,47 @@ def main():
         frames_h, pts_h = make_streams(owned, R)
     frames = torch.from_numpy(frames_h).to(dev)          # (R, S, H, W) resident in HBM
     pts = torch.from_numpy(pts_h).to(dev)
-    ctx = hip.Context.from_torch(local_rank)
-    pyrs = [hip.Pyramid(ctx, S, H, W, MAX_LEVEL) for _ in range(2)]
+    # Two HIP streams per GPU.  The tracker runs on a high-priority stream; the pyramid of the frame
+    # after next is built on a normal-priority one, so its workgroups are dispatched where the
+    # tracker leaves room -- in practice while the tracker's last workgroups drain.  Three pyramid
+    # slots: step k tracks slot k%3 -> (k+1)%3 while frame k+2 is built into slot (k+2)%3, which
+    # the tracker of step k-1 was the last to read.  Every step still builds one pyramid and
+    # tracks one frame per stream.
+    if args.no_pipeline:
+        s_klt = s_pyr = torch.cuda.current_stream(dev)
+    else:
+        s_klt = torch.cuda.Stream(device=dev, priority=-1)
+        s_pyr = torch.cuda.Stream(device=dev, priority=0)
+    with torch.cuda.stream(s_klt):
+        ctx = hip.Context.from_torch(local_rank)
+    with torch.cuda.stream(s_pyr):
+        ctx_pyr = hip.Context.from_torch(local_rank)
+    pyrs = [hip.Pyramid(ctx_pyr, S, H, W, MAX_LEVEL) for _ in range(3)]
     out = (torch.empty_like(pts), torch.empty((S, N_KP), dtype=torch.uint8, device=dev),
            torch.empty((S, N_KP), dtype=torch.float32, device=dev))
+    pyr_done = [torch.cuda.Event() for _ in range(3)]
+    klt_done = [torch.cuda.Event() for _ in range(3)]
+    torch.cuda.synchronize()
 
     state = {"t": 0}
-    pyrs[0].build(frames[0])
+    for f in (0, 1):
+        pyrs[f].build(frames[f % R])
+        pyr_done[f].record(s_pyr)
+    klt_done[2].record(s_klt)      # slot 2 is free from the start
 
     def step(ev=None):
-        t = state["t"]
-        prev, nxt = pyrs[t % 2], pyrs[(t + 1) % 2]
-        nxt.build(frames[(t + 1) % R])
+        k = state["t"]
+        s_pyr.wait_event(klt_done[(k + 2) % 3])          # = step k-1, the last reader of the slot
+        pyrs[(k + 2) % 3].build(frames[(k + 2) % R])
+        pyr_done[(k + 2) % 3].record(s_pyr)
+        s_klt.wait_event(pyr_done[(k + 1) % 3])
         if ev:
-            ev[0].record()
-        hip.klt_track(ctx, prev, nxt, pts, out=out)
+            ev[0].record(s_klt)
+        hip.klt_track(ctx, pyrs[k % 3], pyrs[(k + 1) % 3], pts, out=out)
         if ev:
-            ev[1].record()
-        state["t"] = t + 1
+            ev[1].record(s_klt)
+        klt_done[k % 3].record(s_klt)
+        state["t"] = k + 1
 
     def fence():
         torch.cuda.synchronize()
@@ -208,6 +233,7 @@ def main():
             "config": {"workload": "KITTI-shaped 1241x376 u8 frames, 2000 keypoints/frame, 4-level pyramid "
                                    "(maxLevel=3), win 21, 10 iters, eps 1e-3, minEig 1e-2",
                        "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R,
+                       "schedule": "one stream" if args.no_pipeline else "pyramid of frame k+2 on a second HIP stream during tracker k",
                        "distinct_streams": (args.distinct if args.distinct and args.distinct < S else S) * world,
                        "tracked_fraction": tracked_frac, "parallelism": f"stream-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "klt_track3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
