@@ -536,7 +536,6 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[K3_WAVES * K3_KP_WAVE * K3_REGION];
 
-    const int lane = threadIdx.x & 63;
     const int wid = uniform(threadIdx.x >> 6);
     int bid = blockIdx.x, img, kb;
     if ((A.batch & 7) == 0) {
@@ -549,20 +548,12 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
     }
     const int kp_wave = kb * K3_KP_BLOCK + wid * K3_KP_WAVE;
     if (kp_wave >= A.n) return;
-
-    // lane -> keypoint slot g and window column; lane 63 shadows lane 62 with zero derivative weights
-    const bool active = lane < 63;
-    const int g = lane < 21 ? 0 : (lane < 42 ? 1 : 2);
-    const int col = active ? lane - 21 * g : 20;
-    const bool have = kp_wave + g < A.n;
-    // index of this lane's keypoint (the launch checks that batch * n fits 31 bits); kept as one
-    // register, positions are re-read per level rather than held
-    const int pidx = img * A.n + min(kp_wave + g, A.n - 1);
-    const int e_addr = 4 * (21 * g + 20);   // the lane before the group's first one is e_addr - 84 (groups 1, 2)
-    const bool first = g == 0;
-
+    // index of a lane's keypoint = pbase + kp_wave + slot (the launch checks that batch * n fits
+    // 31 bits).  Everything per lane that only depends on the lane number (slot, column, tile
+    // region, scan addresses) is re-derived from the lane counter at the top of each level:
+    // holding it across the kernel would cost registers at the 96-VGPR limit of 5 waves/SIMD.
+    const int pbase = img * A.n, plast = A.n - 1 - kp_wave;   // wave-uniform
     uint32_t *lds_wave = lds_all + wid * (K3_KP_WAVE * K3_REGION);
-    const uint32_t *region = lds_wave + g * K3_REGION;
 
     float outx = 0.f, outy = 0.f;
     int status = 1;
@@ -574,10 +565,19 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
         const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
         const float sc = (float)(1. / (1 << level));
-        // the barrier keeps the 64-bit addresses below from being hoisted out of the level loop,
-        // where they would occupy registers for the whole kernel
-        int pi = pidx;
-        asm volatile("" : "+v"(pi));
+        // lane -> keypoint slot g and window column; lane 63 shadows lane 62 (it lies outside every
+        // group's scan range, so whatever it computes is never summed).  The barrier keeps these values
+        // and the 64-bit addresses below from being hoisted out of the level loop, where they would
+        // occupy registers for the whole kernel.
+        int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));   // not loop-invariant as far as the optimiser can tell
+        const int g = lane < 21 ? 0 : (lane < 42 ? 1 : 2);
+        const int col = lane < 63 ? lane - 21 * g : 20;
+        const bool have = g <= plast;
+        const int e_addr = 4 * (21 * g + 20);   // the lane before the group's first one is e_addr - 84 (groups 1, 2)
+        const bool first = g == 0;
+        const uint32_t *region = lds_wave + g * K3_REGION;
+        const int pi = pbase + kp_wave + min(g, plast);
         float px = A.prev_pts[2 * (int64_t)pi] * sc, py = A.prev_pts[2 * (int64_t)pi + 1] * sc;
         float nx, ny;
         if (level == A.max_level) {
@@ -610,12 +610,11 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         wave_sync();
         uint32_t Ic[21], IxP[11], IyP[11];
         int a11, a12, a22;
-        const uint32_t wtd = active ? wt : 0u, wbd = active ? wb : 0u;
         const bool interior = ipx >= 0 && ipx + KLT_WIN < L.w && ipy >= 0 && ipy + KLT_WIN < L.h;
         if (__ballot(lvl_ok && !interior) == 0)
-            k3_template<false>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
+            k3_template<false>(region + col, wt, wb, wt, wb, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
         else
-            k3_template<true>(region + col, wt, wb, wtd, wbd, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
+            k3_template<true>(region + col, wt, wb, wt, wb, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
         const float A11 = group_sum21((float)a11, e_addr, first) * FLT_SCALE;
         const float A12 = group_sum21((float)a12, e_addr, first) * FLT_SCALE;
         const float A22 = group_sum21((float)a22, e_addr, first) * FLT_SCALE;
@@ -703,7 +702,10 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         }
     }
 
-    if (have && active && col == 0) {
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int g_e = lane_e / 21;
+    if (lane_e == 21 * g_e && g_e < K3_KP_WAVE && g_e <= plast) {
+        const int pidx = pbase + kp_wave + g_e;
         A.next_pts[2 * (int64_t)pidx] = outx;
         A.next_pts[2 * (int64_t)pidx + 1] = outy;
         A.status[pidx] = (uint8_t)status;
