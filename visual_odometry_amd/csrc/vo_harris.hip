@@ -5,9 +5,9 @@
 // float32 Sobel 3x3 scaled by 1/8 (REFLECT_101), 2x2 un-normalised box sum of
 // the derivative products with offsets {-1,0} (REFLECT_101 on the product maps),
 // R = a*c - b*b - k*(a+c)^2; mode 1 = min-eigenvalue (Shi-Tomasi) response.
-// One workgroup stages a (16+3)x(64+3) image tile in LDS, derives the 17x65
-// derivative tile from it and emits 16x64 responses; image bytes are read once
-// from HBM per tile (+halo), the response is written once.
+// One workgroup stages a (16+3)x(64+3) image tile in LDS and emits 16x64 responses,
+// four per lane, computed in registers; image bytes are read once from HBM per tile
+// (+halo), the response is written once.
 //
 // NMS/top-K: per image (1) max reduction, (2) local maxima above rel_thresh*max
 // in a (2r+1)^2 window (separable running maximum over LDS tiles; ties go to the
@@ -22,8 +22,6 @@
 #define HR_TH 16
 #define HR_IW (HR_TW + 3)
 #define HR_IH (HR_TH + 3)
-#define HR_DW (HR_TW + 1)
-#define HR_DH (HR_TH + 1)
 #define TOPK_MAX 4096
 #define TOPK_THREADS 1024
 // per-image maxima are kept MAXKEY_STRIDE words apart: atomics on neighbouring words queue up at one
@@ -64,69 +62,98 @@ __device__ __forceinline__ float harris_value(float a, float b, float c, float k
     return (ha + hc) - sqrtf((ha - hc) * (ha - hc) + b * b);
 }
 
-// One workgroup: 64 x 16 responses.  The (16+3) x (64+3) image tile is staged as floats (all
-// reads of a lane in flight before the first LDS store), the 17 x 65 Sobel derivatives are
-// formed from it, and every lane finishes four horizontally adjacent responses, which it
-// stores as 16 bytes.
+// One workgroup: 64 x 16 responses.  The (16+3) x (64+3) image tile is staged as floats in LDS
+// (interior tiles: unaligned dword reads, four pixels per item, all of a lane's reads in flight
+// before the first LDS store; border tiles: bytes with REFLECT_101).  A lane then finishes four
+// horizontally adjacent responses entirely in registers: it reads the 4 x 8 floats around them as
+// eight 16-byte LDS reads, forms the row differences / row smoothings once per tile row, the 2 x 5
+// Sobel derivatives and their products from them, and the 2x2 box sums from the products; the
+// expressions and their order are those of the scalar definition, so results are bit-identical
+// to it.  Four responses leave as one 16-byte store.
 __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__restrict__ img, int w, int h,
                                                               int64_t pitch, int64_t istride, float k, int mode,
                                                               float *__restrict__ R, uint32_t *__restrict__ maxkey)
 {
-    __shared__ float tile[HR_IH][HR_IW + 1];
+    constexpr int IS = 68;   // row stride of the tile: 67 columns used, rows 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float tile[HR_IH * IS];
     __shared__ uint32_t wave_max[4];
-    __shared__ float dxs[HR_DH][HR_DW + 1];
-    __shared__ float dys[HR_DH][HR_DW + 1];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * HR_TW, y0 = blockIdx.y * HR_TH;
     const uint8_t *src = img + (int64_t)blockIdx.z * istride;
     float *dst = R + (int64_t)blockIdx.z * w * h;
 
-    {
+    if (x0 - 2 >= 0 && y0 - 2 >= 0 && x0 - 2 + IS <= w && y0 - 2 + HR_IH <= h) {
+        constexpr int ITEMS = HR_IH * (IS / 4), ROUNDS = (ITEMS + 255) / 256;
+        const uint8_t *base = src + (int64_t)(y0 - 2) * pitch + (x0 - 2);
+        uint32_t q[ROUNDS];
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int idx = min(t + 256 * i, ITEMS - 1);
+            const int r = idx / (IS / 4), c = idx - r * (IS / 4);
+            __builtin_memcpy(&q[i], base + (int64_t)r * pitch + 4 * c, 4);
+        }
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int idx = min(t + 256 * i, ITEMS - 1);
+            const float4 f = {(float)(q[i] & 0xffu), (float)((q[i] >> 8) & 0xffu), (float)((q[i] >> 16) & 0xffu), (float)(q[i] >> 24)};
+            *reinterpret_cast<float4 *>(tile + 4 * idx) = f;
+        }
+    } else {
         constexpr int ITEMS = HR_IH * HR_IW, ROUNDS = (ITEMS + 255) / 256;
         uint8_t v[ROUNDS];
 #pragma unroll
-        for (int q = 0; q < ROUNDS; ++q) {
-            const int idx = min(t + 256 * q, ITEMS - 1);
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int idx = min(t + 256 * i, ITEMS - 1);
             const int r = idx / HR_IW, c = idx - r * HR_IW;
-            v[q] = src[(int64_t)refl1(y0 - 2 + r, h) * pitch + refl1(x0 - 2 + c, w)];
+            v[i] = src[(int64_t)refl1(y0 - 2 + r, h) * pitch + refl1(x0 - 2 + c, w)];
         }
 #pragma unroll
-        for (int q = 0; q < ROUNDS; ++q) {
-            const int idx = min(t + 256 * q, ITEMS - 1);
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int idx = min(t + 256 * i, ITEMS - 1);
             const int r = idx / HR_IW, c = idx - r * HR_IW;
-            tile[r][c] = (float)v[q];
+            tile[r * IS + c] = (float)v[i];
         }
     }
     __syncthreads();
-    for (int idx = t; idx < HR_DH * HR_DW; idx += 256) {
-        int r = idx / HR_DW, c = idx - r * HR_DW;   // derivative at image (x0-1+c, y0-1+r) = tile (c+1, r+1)
-        const float *p0 = &tile[r][c], *p1 = &tile[r + 1][c], *p2 = &tile[r + 2][c];
-        float d0 = p0[2] - p0[0], d1 = p1[2] - p1[0], d2 = p2[2] - p2[0];
-        float dx = d1 * 0.25f + (d0 + d2) * 0.125f;
-        float s0 = p0[1] * 0.25f + (p0[0] + p0[2]) * 0.125f;
-        float s2 = p2[1] * 0.25f + (p2[0] + p2[2]) * 0.125f;
-        float dy = s2 - s0;
-        // positions left of / above the image stand for the product maps at the
-        // mirrored coordinate: undo the sign the mirrored image gives the odd part
-        if (x0 - 1 + c < 0) dx = -dx;
-        if (y0 - 1 + r < 0) dy = -dy;
-        dxs[r][c] = dx;
-        dys[r][c] = dy;
-    }
-    __syncthreads();
+
     const int tx = (t & 15) * 4, ty = t >> 4;
     const int gx = x0 + tx, gy = y0 + ty;
     const bool inside = gx < w && gy < h;
-    if (!inside && !maxkey) return;
+    float p[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 lo = *reinterpret_cast<const float4 *>(tile + (ty + r) * IS + tx);
+        const float4 hi = *reinterpret_cast<const float4 *>(tile + (ty + r) * IS + tx + 4);
+        p[r][0] = lo.x; p[r][1] = lo.y; p[r][2] = lo.z; p[r][3] = lo.w;
+        p[r][4] = hi.x; p[r][5] = hi.y; p[r][6] = hi.z; p[r][7] = hi.w;
+    }
+    // derivative (dr, c) sits at image (gx - 1 + c, gy - 1 + dr) and uses tile rows dr..dr+2, columns c..c+2
+    float pxx[2][5], pxy[2][5], pyy[2][5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        float hd[4], hs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hd[r] = p[r][c + 2] - p[r][c];
+            hs[r] = p[r][c + 1] * 0.25f + (p[r][c] + p[r][c + 2]) * 0.125f;
+        }
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr) {
+            float dx = hd[dr + 1] * 0.25f + (hd[dr] + hd[dr + 2]) * 0.125f;
+            float dy = hs[dr + 2] - hs[dr];
+            // one pixel left of / above the image the product maps are mirrored: undo the sign the
+            // mirrored image gives the odd derivative
+            if (gx - 1 + c < 0) dx = -dx;
+            if (gy - 1 + dr < 0) dy = -dy;
+            pxx[dr][c] = dx * dx; pxy[dr][c] = dx * dy; pyy[dr][c] = dy * dy;
+        }
+    }
     float out[4];
     uint32_t mk = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float a, b, c;
-        float ax = dxs[ty][tx + j], ay = dys[ty][tx + j], bx = dxs[ty][tx + j + 1], by = dys[ty][tx + j + 1];
-        a = ax * ax + bx * bx; b = ax * ay + bx * by; c = ay * ay + by * by;
-        ax = dxs[ty + 1][tx + j]; ay = dys[ty + 1][tx + j]; bx = dxs[ty + 1][tx + j + 1]; by = dys[ty + 1][tx + j + 1];
-        float ra = ax * ax + bx * bx, rb = ax * ay + bx * by, rc = ay * ay + by * by;
+        float a = pxx[0][j] + pxx[0][j + 1], b = pxy[0][j] + pxy[0][j + 1], c = pyy[0][j] + pyy[0][j + 1];
+        const float ra = pxx[1][j] + pxx[1][j + 1], rb = pxy[1][j] + pxy[1][j + 1], rc = pyy[1][j] + pyy[1][j + 1];
         a = a + ra; b = b + rb; c = c + rc;
         out[j] = harris_value(a, b, c, k, mode);
         if (inside && gx + j < w) mk = max(mk, ordered_key(out[j]));
@@ -141,7 +168,7 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
     }
     if (maxkey) {
         // per-image maximum of the response (as ordered keys) for the detector's relative threshold:
-        // one atomic per workgroup
+        // at most one atomic per workgroup
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, o));
         if ((t & 63) == 0) wave_max[t >> 6] = mk;
@@ -149,7 +176,6 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t *__r
         if (t == 0) raise_max(&maxkey[blockIdx.z * MAXKEY_STRIDE], max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
     }
 }
-
 
 __global__ __launch_bounds__(256) void max_key_kernel(const float *__restrict__ R, int64_t npix, uint32_t *__restrict__ maxkey)
 {
