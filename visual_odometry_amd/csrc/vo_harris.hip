@@ -388,10 +388,23 @@ static void launch_nms_tile(hipStream_t stream, dim3 grid, size_t lds, const flo
 // collected in LDS when they fit (TOPK_POOL keys; otherwise every pass re-reads the slots from memory), the
 // K-th largest key is found by radix selection (8 x 8-bit passes), the winners are gathered and
 // bitonic-sorted.  Keys are unique, so the result does not depend on the order of the list.
+// Position in a list for every lane with `take` set (-1 otherwise): one LDS atomic per wavefront.
+__device__ __forceinline__ int wave_append(bool take, int *counter)
+{
+    const unsigned long long m = __ballot(take);
+    if (m == 0) return -1;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(counter, __builtin_popcountll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    return take ? base + __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 template <bool POOLED>
 __device__ __forceinline__ void topk_body(const unsigned long long *__restrict__ c, const unsigned long long *pool, int n,
                                           int valid, int w,
-                                          int K, unsigned long long *sel, int *hist, unsigned long long *s_prefix, int *s_need,
+                                          int K, unsigned long long *sel, int *hist, int *wave_tot,
+                                          unsigned long long *s_prefix, int *s_need,
                                           int *s_nsel, float *__restrict__ xy, float *__restrict__ scores,
                                           int *__restrict__ count, int b)
 {
@@ -410,14 +423,28 @@ __device__ __forceinline__ void topk_body(const unsigned long long *__restrict__
                 if ((POOLED || key != 0ull) && (key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
             }
             __syncthreads();
-            if (t == 0) {
-                int need = *s_need, bin = 255;
-                for (; bin > 0; --bin) {
-                    if (hist[bin] >= need) break;
-                    need -= hist[bin];
+            // the bin that holds the need-th largest key: suffix sums of the histogram over the first
+            // 256 lanes (shuffles inside a wavefront, the wavefront totals through LDS); bin b is the
+            // one with suffix(b) >= need > suffix(b + 1)
+            const int need = *s_need;
+            int suf = 0;
+            if (t < 256) {
+                suf = hist[t];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_down(suf, o);
+                    if ((t & 63) + o < 64) suf += up;
                 }
-                *s_need = need;
-                *s_prefix = prefix | ((unsigned long long)bin << shift);
+                if ((t & 63) == 0) wave_tot[t >> 6] = suf;
+            }
+            __syncthreads();
+            if (t < 256) {
+                const int own = hist[t];
+                for (int wv = (t >> 6) + 1; wv < 4; ++wv) suf += wave_tot[wv];
+                if (suf >= need && suf - own < need) {      // exactly one lane (need >= 1, total >= need)
+                    *s_need = need - (suf - own);
+                    *s_prefix = prefix | ((unsigned long long)t << shift);
+                }
             }
             __syncthreads();
         }
@@ -426,12 +453,11 @@ __device__ __forceinline__ void topk_body(const unsigned long long *__restrict__
     if (t == 0) *s_nsel = 0;
     for (int i = t; i < TOPK_MAX; i += TOPK_THREADS) sel[i] = 0;
     __syncthreads();
-    for (int i = t; i < n; i += TOPK_THREADS) {
-        const unsigned long long key = POOLED ? pool[i] : c[i];
-        if (key >= T) {
-            const int pos = atomicAdd(s_nsel, 1);
-            if (pos < TOPK_MAX) sel[pos] = key;
-        }
+    for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+        const int i = i0 + t;
+        const unsigned long long key = i < n ? (POOLED ? pool[i] : c[i]) : 0ull;
+        const int pos = wave_append(key >= T && key != 0ull, s_nsel);
+        if (pos >= 0 && pos < TOPK_MAX) sel[pos] = key;
     }
     __syncthreads();
     // bitonic sort, descending, over the next power of two >= m
@@ -471,34 +497,35 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const unsigned long 
     extern __shared__ __attribute__((aligned(16))) unsigned long long pool[];   // TOPK_POOL keys
     __shared__ unsigned long long sel[TOPK_MAX];
     __shared__ int hist[256];
+    __shared__ int wave_tot[4];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_need, s_nsel;
     const int b = blockIdx.x, t = threadIdx.x;
     const unsigned long long *c = cand + (int64_t)b * cap;
     if (t == 0) s_nsel = 0;
     __syncthreads();
-    // one pass over the slots: filled ones go to the pool (in no particular order) and are counted
-    for (int i0 = 0; i0 < cap; i0 += 4 * TOPK_THREADS) {
-        unsigned long long k4[4];
+    // one pass over the slots, up to 16 reads in flight per lane: filled ones go to the pool (in no
+    // particular order) and are counted
+    for (int i0 = 0; i0 < cap; i0 += 16 * TOPK_THREADS) {
+        unsigned long long k16[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int i = i0 + u * TOPK_THREADS + t;
-            k4[u] = i < cap ? c[i] : 0ull;
+            k16[u] = i < cap ? c[i] : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (k4[u] != 0ull) {
-                const int pos = atomicAdd(&s_nsel, 1);
-                if (pos < TOPK_POOL) pool[pos] = k4[u];
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int pos = wave_append(k16[u] != 0ull, &s_nsel);
+            if (pos >= 0 && pos < TOPK_POOL) pool[pos] = k16[u];
+        }
     }
     __syncthreads();
     const int valid = s_nsel;
     __syncthreads();
     if (valid <= TOPK_POOL)
-        topk_body<true>(c, pool, valid, valid, w, K, sel, hist, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
+        topk_body<true>(c, pool, valid, valid, w, K, sel, hist, wave_tot, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
     else
-        topk_body<false>(c, pool, cap, valid, w, K, sel, hist, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
+        topk_body<false>(c, pool, cap, valid, w, K, sel, hist, wave_tot, &s_prefix, &s_need, &s_nsel, xy, scores, count, b);
 }
 
 extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
