@@ -48,6 +48,25 @@ def test_pyramid_bit_exact(oracle, ctx, shape):
             np.testing.assert_array_equal(pyr.download(b, l), oracle.pyr_level(imgs[b], l))
 
 
+@pytest.mark.parametrize("batch,shape", [(8, (50, 91)), (16, (44, 45)), (8, (376, 1241)), (5, (45, 44)), (1, (23, 300))])
+def test_pyramid_batches_and_strides(oracle, ctx, batch, shape):
+    """Batches that take the image-per-XCD workgroup order (multiples of 8) and those that do not, the narrowest
+    levels, and device input whose rows and images are padded (strides larger than the image)."""
+    import torch
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(batch)
+    h, w = shape
+    big = torch.from_numpy(rng.integers(0, 256, (batch, h + 3, w + 5), dtype=np.uint8)).cuda()
+    view = big[:, 1:1 + h, 2:2 + w]                     # row stride w + 5, image stride (h + 3) * (w + 5)
+    pyr = hip.Pyramid(ctx, batch, h, w, 8).build(view)
+    ctx.sync()
+    imgs = view.cpu().numpy()
+    assert pyr.max_level == oracle.pyr_max_level(w, h, 8)
+    for b in {0, batch // 2, batch - 1}:
+        for l in range(pyr.max_level + 1):
+            np.testing.assert_array_equal(pyr.download(b, l), oracle.pyr_level(imgs[b], l))
+
+
 def test_pyramid_device_input(oracle, ctx):
     import torch
     from visual_odometry_amd import hip
