@@ -243,6 +243,32 @@ int vo_ransac_draw_subsets(uint64_t *rng_state, int count, int model_points, int
 int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n, const uint8_t *mask, const double *K,
                    const double *pose_in, int max_iters, double *pose_out, double *cost_out, int mem);
 
+/* ---- whole RANSAC calls ---------------------------------------------------------------
+ * vo_solve_pnp_ransac replaces cv.solvePnPRansac(pointcloud, img_key_points, K, None,
+ * flags=SOLVEPNP_P3P, reprojectionError=thr, confidence=conf, iterationsCount=max_iters)
+ * at vo_pipeline/poseEstimation.py:61-69 in one call: max_iters four-point samples drawn as
+ * OpenCV draws them, every P3P candidate solved and scored on the GPU (candidates never
+ * leave the device), OpenCV's sequential loop -- best-so-far update, adaptive iteration
+ * count -- replayed on the host over the inlier counts, and a Gauss-Newton refit of the
+ * winner on its inliers (refine_iters; OpenCV refits with EPnP there).  X (n,3) float32,
+ * x (n,2) float32 and inlier_mask (n) uint8 follow `mem`; K (3,3) float64, rng_state
+ * (in/out cv::RNG state, NULL = OpenCV's initial 2^64-1), Rt_out (3,4) float64 [R|t]
+ * world->camera and n_inliers are host pointers.  n_inliers = 0: no pose found (the
+ * condition under which cv2 returns success = False).  Synchronises the stream.
+ *
+ * vo_find_fundamental_ransac replaces cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC, thr,
+ * conf, max_iters) at vo_pipeline/bootstrap.py:246-252 the same way (7-point candidates, up
+ * to three per sample; no refit, as in OpenCV).  m1, m2 (n,2) float32, F_out (3,3) float64,
+ * inlier_mask (n) uint8 and n_inliers are host pointers (the sampler's collinearity test
+ * reads the points on the host).
+ */
+int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, int n, const double *K, double thr,
+                        double conf, int max_iters, int refine_iters, uint64_t *rng_state, double *Rt_out,
+                        uint8_t *inlier_mask, int32_t *n_inliers, int mem);
+int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, int n, double thr, double conf,
+                               int max_iters, uint64_t *rng_state, double *F_out, uint8_t *inlier_mask,
+                               int32_t *n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

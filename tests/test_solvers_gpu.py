@@ -160,3 +160,43 @@ def test_refine_pose_one_launch(oracle, ctx):
     assert c0 == pytest.approx(ref0, rel=1e-9)
     with pytest.raises(ValueError):
         hip.refine_pose(ctx, X, x[:-1], K, rv0, t0)
+
+
+@pytest.mark.parametrize("max_iters", [100, 2000])
+def test_fused_ransac_calls_match_stepwise(ctx, max_iters):
+    """vo_find_fundamental_ransac / vo_solve_pnp_ransac (candidates resident on the device, loop replayed in C)
+    against the same computation spelled out over the single-step entry points."""
+    from visual_odometry_amd.vo_pipeline import ransac
+    sc = synth.two_view_scene(n=1500, seed=21)
+    F1, m1 = ransac.find_fundamental_mat(sc["m1"], sc["m2"], 0.5, 0.999, max_iters)
+    F2, m2 = ransac.find_fundamental_mat_stepwise(sc["m1"], sc["m2"], 0.5, 0.999, max_iters)
+    assert F1 is not None and m1.shape == (1500, 1) and m1.dtype == np.uint8
+    np.testing.assert_array_equal(F1, F2)
+    np.testing.assert_array_equal(m1, m2)
+    ok1, R1, t1, i1 = ransac.solve_pnp_ransac(sc["X"], sc["m2"], sc["K"], 1.0, 0.999, max_iters)
+    ok2, R2, t2, i2 = ransac.solve_pnp_ransac_stepwise(sc["X"], sc["m2"], sc["K"], 1.0, 0.999, max_iters)
+    assert ok1 and ok2 and i1.dtype == np.int32 and i1.shape[1] == 1
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_allclose(R1, R2, atol=1e-9)          # rotation-vector round trips differ in the last bits
+    np.testing.assert_allclose(t1, t2, atol=1e-9)
+    assert np.abs(R1 - sc["R"]).max() < 2e-3 and np.abs(t1 - sc["t"]).max() < 2e-2
+
+
+def test_fused_ransac_degenerate_inputs(ctx):
+    from visual_odometry_amd import hip
+    from visual_odometry_amd.vo_pipeline import ransac
+    sc = synth.two_view_scene(n=40, seed=3)
+    F, mask = ransac.find_fundamental_mat(sc["m1"][:7], sc["m2"][:7], 0.5, 0.99, 50)       # too few points
+    assert F is None and mask.shape == (7, 1) and not mask.any()
+    ok, R, t, inl = ransac.solve_pnp_ransac(sc["X"][:3], sc["m2"][:3], sc["K"], 1.0, 0.99, 50)
+    assert not ok and inl.shape == (0, 1)
+    rng = np.random.default_rng(0)                                                       # no consistent pose at all
+    Rt, mask, good, state = hip.solve_pnp_ransac(ctx, rng.normal(0, 1, (30, 3)), rng.uniform(0, 500, (30, 2)), sc["K"],
+                                                 0.01, 0.99, 20)
+    assert good == int(mask.sum()) and (Rt is None) == (good == 0) and state != 0xFFFFFFFFFFFFFFFF
+    # the generator state continues across calls: a second call draws different samples
+    a = hip.find_fundamental_ransac(ctx, sc["m1"], sc["m2"], 0.5, 0.99, 30)
+    b = hip.find_fundamental_ransac(ctx, sc["m1"], sc["m2"], 0.5, 0.99, 30, rng_state=a[3])
+    assert a[3] != b[3]
+    with pytest.raises(ValueError):
+        hip.solve_pnp_ransac(ctx, sc["X"], sc["m2"][:-1], sc["K"], 1.0, 0.99, 10)

@@ -73,6 +73,12 @@ SIGNATURES = {
     "vo_ba_params": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int]),
     "vo_ransac_draw_subsets": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
                                               c_vp, ctypes.c_int, c_vp]),
+    "vo_solve_pnp_ransac": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), c_f64p, c_vp,
+                                           ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
+    "vo_find_fundamental_ransac": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), c_f64p, c_vp,
+                                                  ctypes.POINTER(ctypes.c_int32)]),
     "vo_refine_pose": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p,
                                       ctypes.c_int]),
 }

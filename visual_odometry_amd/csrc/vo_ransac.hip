@@ -9,6 +9,8 @@
 #include "vo_internal.h"
 #include <math.h>
 #include <float.h>
+#include <memory>
+#include <new>
 
 static inline uint32_t cv_rng_next(uint64_t &s)
 {
@@ -56,5 +58,209 @@ extern "C" int vo_ransac_draw_subsets(uint64_t *rng_state, int count, int model_
         for (int k = 0; k < model_points; ++k) subsets[(size_t)q * model_points + k] = idx[k];
     }
     *rng_state = s;
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Whole RANSAC calls.  One entry point stands in for one cv2 call: all samples are
+// drawn up front (above), the GPU solves every minimal problem and scores every
+// candidate against every correspondence (two launches, candidates and points stay
+// on the device), the host reads back one inlier count per candidate and replays
+// OpenCV's sequential loop over them -- best-so-far update, adaptive iteration
+// count, early stop -- so the outcome equals that loop run on the same candidate
+// sequence; a third launch produces the winner's inlier mask.
+// ---------------------------------------------------------------------------
+
+// RANSACUpdateNumIters: iterations needed for confidence p at outlier ratio ep
+static int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = fmin(fmax(p, 0.), 1.);
+    ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)lrint(num / denom);
+}
+
+// counts: per_sample candidates per iteration (unused slots flagged by used[] == 0).  Returns the winning
+// candidate index or -1.
+static int replay_ransac_loop(const int32_t *counts, const uint8_t *used, int per_sample, int n, int model_points,
+                              double conf, int max_iters)
+{
+    int niters = max_iters, best = -1, best_c = -1;
+    for (int it = 0; it < niters; ++it)
+        for (int s = 0; s < per_sample; ++s) {
+            const int c = it * per_sample + s;
+            if (!used[c]) continue;
+            const int good = counts[c];
+            if (good > (best > model_points - 1 ? best : model_points - 1)) {
+                best = good;
+                best_c = c;
+                niters = ransac_update_num_iters(conf, (double)(n - good) / n, model_points, niters);
+            }
+        }
+    return best_c;
+}
+
+static void rotvec_from_matrix(const double *R, double *rv)
+{
+    // via the unit quaternion (largest component first, for accuracy near 0 and pi)
+    const double tr = R[0] + R[4] + R[8];
+    double q[4];   // x, y, z, w
+    if (tr > R[0] && tr > R[4] && tr > R[8]) {
+        q[3] = 1. + tr; q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1];
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {
+        q[0] = 1. + 2. * R[0] - tr; q[1] = R[1] + R[3]; q[2] = R[2] + R[6]; q[3] = R[7] - R[5];
+    } else if (R[4] >= R[8]) {
+        q[1] = 1. + 2. * R[4] - tr; q[0] = R[1] + R[3]; q[2] = R[5] + R[7]; q[3] = R[2] - R[6];
+    } else {
+        q[2] = 1. + 2. * R[8] - tr; q[0] = R[2] + R[6]; q[1] = R[5] + R[7]; q[3] = R[3] - R[1];
+    }
+    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) q[k] /= nq;
+    if (q[3] < 0) for (int k = 0; k < 4; ++k) q[k] = -q[k];
+    const double sn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    const double angle = 2. * atan2(sn, q[3]);
+    const double scale = sn < 1e-12 ? 2. : angle / sn;     // angle / sin(angle / 2) -> 2
+    for (int k = 0; k < 3; ++k) rv[k] = scale * q[k];
+}
+
+static void matrix_from_rotvec(const double *rv, double *R)
+{
+    const double th = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (th == 0) { for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0); return; }
+    const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1. - c;
+    R[0] = c + v * kx * kx;      R[1] = v * kx * ky - s * kz; R[2] = v * kx * kz + s * ky;
+    R[3] = v * kx * ky + s * kz; R[4] = c + v * ky * ky;      R[5] = v * ky * kz - s * kx;
+    R[6] = v * kx * kz - s * ky; R[7] = v * ky * kz + s * kx; R[8] = c + v * kz * kz;
+}
+
+extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, int n, const double *K, double thr,
+                                   double conf, int max_iters, int refine_iters, uint64_t *rng_state, double *Rt_out,
+                                   uint8_t *inlier_mask, int32_t *n_inliers, int mem)
+{
+    VO_REQUIRE(ctx && K && Rt_out && inlier_mask && n_inliers, "vo_solve_pnp_ransac: NULL argument");
+    VO_REQUIRE(n >= 0 && (n == 0 || (X && x)), "vo_solve_pnp_ransac: bad point buffers (n=%d)", n);
+    VO_REQUIRE(max_iters >= 1 && max_iters <= (1 << 22) && refine_iters >= 0, "vo_solve_pnp_ransac: max_iters=%d refine_iters=%d", max_iters, refine_iters);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_solve_pnp_ransac: bad mem flag %d", mem);
+    *n_inliers = 0;
+    if (n < 4) return VO_OK;
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const int S = max_iters;
+    int rc;
+    void *p;
+    uint64_t state = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    std::unique_ptr<int32_t[]> subsets_buf(new (std::nothrow) int32_t[(size_t)S * 4]);
+    std::unique_ptr<int32_t[]> counts_buf(new (std::nothrow) int32_t[(size_t)S * 2]);     // S counts, then S validity flags (bytes)
+    if (!subsets_buf || !counts_buf) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
+    int32_t *subsets = subsets_buf.get(), *counts = counts_buf.get();
+    uint8_t *valid = (uint8_t *)(counts + S);
+    if ((rc = vo_ransac_draw_subsets(&state, n, 4, S, nullptr, nullptr, 1, subsets))) return rc;
+    if (rng_state) *rng_state = state;
+    const float *dX = X, *dx = x;
+    uint8_t *dmask = inlier_mask;
+    // staging slots 0, 1 (points), 2 (subsets), 4 (candidates), 5 (counts + flags), 6 (mask); slot 3 belongs to vo_refine_pose
+    if (mem == VO_MEM_HOST) {
+        if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 12, &p))) return rc; dX = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc; dx = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc; dmask = (uint8_t *)p;
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 16, &p))) return rc;
+    int32_t *dsub = (int32_t *)p;
+    if ((rc = vo_stage_reserve(ctx, 4, (size_t)S * 96, &p))) return rc;
+    double *dRt = (double *)p;
+    if ((rc = vo_stage_reserve(ctx, 5, (size_t)S * 5 + 16, &p))) return rc;
+    int32_t *dcounts = (int32_t *)p;
+    uint8_t *dvalid = (uint8_t *)(dcounts + S);
+    VO_HIP_CHECK(hipMemcpyAsync(dsub, subsets, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub, S, dRt, dvalid, VO_MEM_DEVICE))) return rc;
+    if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt, S, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts, (size_t)S * 5, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int win = replay_ransac_loop(counts, valid, 1, n, 4, conf, max_iters);
+    if (win < 0) return VO_OK;
+    double Rt[12];
+    int32_t good = 0;
+    if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)win * 12, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(Rt, dRt + (size_t)win * 12, sizeof(Rt), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(&good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipMemcpyAsync(inlier_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (good >= 4 && refine_iters > 0) {
+        // refit on the inliers (OpenCV refits with EPnP there; here Gauss-Newton on the same error)
+        double R[9], pose[6], out[6], cost;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = Rt[4 * r + c];
+        rotvec_from_matrix(R, pose);
+        pose[3] = Rt[3]; pose[4] = Rt[7]; pose[5] = Rt[11];
+        if ((rc = vo_refine_pose(ctx, dX, dx, n, dmask, K, pose, refine_iters, out, &cost, VO_MEM_DEVICE))) return rc;
+        bool finite = true;
+        for (int k = 0; k < 6; ++k) finite = finite && isfinite(out[k]);
+        if (finite) {
+            matrix_from_rotvec(out, R);
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[4 * r + c] = R[3 * r + c]; Rt[4 * r + 3] = out[3 + r]; }
+        }
+    }
+    memcpy(Rt_out, Rt, sizeof(Rt));
+    *n_inliers = good;
+    return VO_OK;
+}
+
+extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, int n, double thr, double conf,
+                                          int max_iters, uint64_t *rng_state, double *F_out, uint8_t *inlier_mask,
+                                          int32_t *n_inliers)
+{
+    VO_REQUIRE(ctx && F_out && inlier_mask && n_inliers, "vo_find_fundamental_ransac: NULL argument");
+    VO_REQUIRE(n >= 0 && (n == 0 || (m1 && m2)), "vo_find_fundamental_ransac: bad point buffers (n=%d)", n);
+    VO_REQUIRE(max_iters >= 1 && max_iters <= (1 << 22), "vo_find_fundamental_ransac: max_iters=%d", max_iters);
+    *n_inliers = 0;
+    if (n < 8) return VO_OK;   // OpenCV needs >= 7 and switches estimators below 15; the RANSAC form is kept for n >= 8
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const int S = max_iters;
+    int rc;
+    void *p;
+    uint64_t state = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    std::unique_ptr<int32_t[]> subsets_buf(new (std::nothrow) int32_t[(size_t)S * 7]);
+    std::unique_ptr<int32_t[]> counts_buf(new (std::nothrow) int32_t[(size_t)S * 5]);     // 3S counts, S solution counts, 3S flags (bytes)
+    if (!subsets_buf || !counts_buf) { vo_set_error("vo_find_fundamental_ransac: out of host memory"); return VO_ENOMEM; }
+    int32_t *subsets = subsets_buf.get(), *counts = counts_buf.get();
+    // the collinearity test of the sampler reads the points on the host
+    if ((rc = vo_ransac_draw_subsets(&state, n, 7, S, m1, m2, 10000, subsets))) return rc;
+    if (rng_state) *rng_state = state;
+    if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 8, &p))) return rc;
+    float *d1 = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc;
+    float *d2 = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 28, &p))) return rc;
+    int32_t *dsub = (int32_t *)p;
+    if ((rc = vo_stage_reserve(ctx, 4, (size_t)S * 216, &p))) return rc;
+    double *dF = (double *)p;
+    if ((rc = vo_stage_reserve(ctx, 5, (size_t)S * 16 + 16, &p))) return rc;
+    int32_t *dcounts = (int32_t *)p, *dnsol = dcounts + 3 * (size_t)S;
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc;
+    uint8_t *dmask = (uint8_t *)p;
+    VO_HIP_CHECK(hipMemcpyAsync(d1, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(d2, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(dsub, subsets, (size_t)S * 28, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub, S, dF, dnsol, VO_MEM_DEVICE))) return rc;
+    if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF, 3 * S, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts, (size_t)S * 16, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int32_t *nsol = counts + 3 * (size_t)S;
+    uint8_t *used = (uint8_t *)(counts + 4 * (size_t)S);
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < 3; ++k) used[3 * s + k] = k < nsol[s];
+    const int win = replay_ransac_loop(counts, used, 3, n, 7, conf, max_iters);
+    if (win < 0) return VO_OK;
+    int32_t good = 0;
+    if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)win * 9, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(F_out, dF + (size_t)win * 9, 72, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(&good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(inlier_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_inliers = good;
     return VO_OK;
 }

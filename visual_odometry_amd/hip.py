@@ -583,3 +583,46 @@ def refine_pose(ctx: Context, X, x, K, rvec, t, mask=None, max_iters: int = 10):
                                  Kd.ctypes.data_as(_lib.c_f64p), start.ctypes.data_as(_lib.c_f64p), int(max_iters),
                                  out.ctypes.data_as(_lib.c_f64p), ctypes.byref(cost), mem), "vo_refine_pose")
     return out[:3].copy(), out[3:].copy(), cost.value
+
+
+def solve_pnp_ransac(ctx: Context, X, x, K, thr: float, conf: float, max_iters: int, refine_iters: int = 10,
+                     rng_state: Optional[int] = None):
+    """Whole PnP-RANSAC call (P3P candidates, OpenCV's loop replayed, refit on the inliers) ->
+    (Rt (3,4) f64 or None, inlier mask (n,) u8, number of inliers, rng state after the draws)."""
+    Kh = _k_host(K)
+    if _is_torch(X):
+        import torch
+        X = X.reshape(-1, 3).contiguous(); x = x.reshape(-1, 2).contiguous()
+        mask = torch.zeros(X.shape[0], dtype=torch.uint8, device=X.device)
+        mem = VO_MEM_DEVICE
+    else:
+        X = np.ascontiguousarray(X, np.float32).reshape(-1, 3); x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
+        mask = np.zeros(X.shape[0], np.uint8)
+        mem = VO_MEM_HOST
+    n = int(X.shape[0])
+    if int(x.shape[0]) != n:
+        raise ValueError("solve_pnp_ransac: point sets differ in length")
+    state = ctypes.c_uint64(0xFFFFFFFFFFFFFFFF if rng_state is None else rng_state)
+    Rt = np.zeros((3, 4))
+    good = ctypes.c_int32()
+    check(ctx.lib.vo_solve_pnp_ransac(ctx.handle, _ptr(X), _ptr(x), n, Kh.ctypes.data_as(_lib.c_f64p), float(thr), float(conf),
+                                      int(max_iters), int(refine_iters), ctypes.byref(state), Rt.ctypes.data_as(_lib.c_f64p),
+                                      _ptr(mask), ctypes.byref(good), mem), "vo_solve_pnp_ransac")
+    return (Rt if good.value > 0 else None), mask, int(good.value), int(state.value)
+
+
+def find_fundamental_ransac(ctx: Context, m1, m2, thr: float, conf: float, max_iters: int, rng_state: Optional[int] = None):
+    """Whole fundamental-matrix RANSAC call (7-point candidates, OpenCV's loop replayed, no refit) ->
+    (F (3,3) f64 or None, inlier mask (n,) u8, number of inliers, rng state after the draws).  Host arrays."""
+    m1 = np.ascontiguousarray(m1, np.float32).reshape(-1, 2); m2 = np.ascontiguousarray(m2, np.float32).reshape(-1, 2)
+    n = int(m1.shape[0])
+    if int(m2.shape[0]) != n:
+        raise ValueError("find_fundamental_ransac: point sets differ in length")
+    state = ctypes.c_uint64(0xFFFFFFFFFFFFFFFF if rng_state is None else rng_state)
+    F = np.zeros((3, 3))
+    mask = np.zeros(n, np.uint8)
+    good = ctypes.c_int32()
+    check(ctx.lib.vo_find_fundamental_ransac(ctx.handle, _ptr(m1), _ptr(m2), n, float(thr), float(conf), int(max_iters),
+                                             ctypes.byref(state), F.ctypes.data_as(_lib.c_f64p), _ptr(mask),
+                                             ctypes.byref(good)), "vo_find_fundamental_ransac")
+    return (F if good.value > 0 else None), mask, int(good.value), int(state.value)

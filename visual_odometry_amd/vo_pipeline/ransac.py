@@ -11,6 +11,11 @@ sample per lane) and scores every candidate against every correspondence in one
 launch (vo_score_fundamental / vo_score_pnp), and the host replays OpenCV's
 sequential loop over the counts -- best-so-far update, adaptive iteration count,
 early stop -- so the outcome equals that loop run on the same candidate sequence.
+find_fundamental_mat / solve_pnp_ransac make one library call each
+(vo_find_fundamental_ransac / vo_solve_pnp_ransac: candidates stay on the device,
+the loop is replayed in C); the *_stepwise functions are the same computation
+spelled out over the single-step entry points, for callers that bring their own
+candidates and as the executable statement the parity tests hold the fused calls to.
 The minimal solvers are independent implementations (same geometry, different
 numerics than OpenCV's), so candidates agree with cv2 only to solver precision.
 """
@@ -82,6 +87,13 @@ def replay_ransac_loop(counts: np.ndarray, owner: np.ndarray, n: int, model_poin
 def find_fundamental_mat(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: float, max_iters: int,
                          device: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
     """-> (F (3,3) float64 or None, mask (n,1) uint8), as cv2.findFundamentalMat(..., FM_RANSAC, ...)."""
+    F, mask, _, _ = hip.find_fundamental_ransac(_runtime.context(device), pts0, pts1, thr, conf, int(max_iters))
+    return F, mask.reshape(-1, 1)
+
+
+def find_fundamental_mat_stepwise(pts0: np.ndarray, pts1: np.ndarray, thr: float, conf: float, max_iters: int,
+                                  device: int = 0) -> Tuple[Optional[np.ndarray], np.ndarray]:
+    """find_fundamental_mat out of the single-step entry points (sampler, 7-point solver, scoring, replay)."""
     m1 = np.ascontiguousarray(pts0, np.float32).reshape(-1, 2)
     m2 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
     n = m1.shape[0]
@@ -120,6 +132,15 @@ def solve_pnp_ransac(X: np.ndarray, x: np.ndarray, K: np.ndarray, thr: float, co
                      device: int = 0):
     """-> (success, R (3,3), t (3,), inliers (k,1) int32), as cv.solvePnPRansac(flags=SOLVEPNP_P3P)
     followed by its refit on the inliers (OpenCV refits with EPnP; here Gauss-Newton on the same error)."""
+    Rt, mask, good, _ = hip.solve_pnp_ransac(_runtime.context(device), X, x, K, thr, conf, int(max_iters), refine_iters=10)
+    if Rt is None:
+        return False, np.eye(3), np.zeros(3), np.zeros((0, 1), np.int32)
+    return True, Rt[:, :3].copy(), Rt[:, 3].copy(), np.nonzero(mask)[0].astype(np.int32).reshape(-1, 1)
+
+
+def solve_pnp_ransac_stepwise(X: np.ndarray, x: np.ndarray, K: np.ndarray, thr: float, conf: float, max_iters: int,
+                              device: int = 0):
+    """solve_pnp_ransac out of the single-step entry points (sampler, P3P solver, scoring, replay, refit)."""
     X = np.ascontiguousarray(X, np.float32).reshape(-1, 3)
     x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
     n = X.shape[0]
