@@ -21,13 +21,13 @@ from visual_odometry_amd.vo_pipeline.continuousVO import ContinuousVO      # noq
 
 def trajectory_error(vo, gt_poses, first):
     """Camera centres of frames >= first in the frame-0 camera system, estimated vs ground truth,
-    after fixing the one free scale on the bootstrap frame.  -> (rms position error / path length,
+    after fitting the one free scale by least squares over the path.  -> (rms position error / path length,
     max rotation error in degrees)."""
     est = {fs.idx: np.asarray(fs.pose, np.float64) for fs in vo.frame_queue.queue}
     idx = sorted(i for i in est if i >= first)
     c_est = np.array([hom_inv(est[i])[:3, 3] for i in idx])
     c_gt = np.array([gt_poses[i][:3, 3] for i in idx])
-    scale = np.linalg.norm(c_gt[0]) / np.linalg.norm(c_est[0])
+    scale = float((c_gt * c_est).sum() / (c_est * c_est).sum())
     err = np.linalg.norm(c_est * scale - c_gt, axis=1)
     rot = []
     for i in idx:

@@ -737,17 +737,23 @@ static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
     return VO_OK;
 }
 
-// Two tracker kernels with identical semantics: three keypoints per wavefront (default) and
-// one keypoint per wavefront (environment VO_KLT_VARIANT=1, kept for comparison runs).
-static int klt_variant()
+// Two tracker kernels with identical semantics.  Three keypoints per wavefront issues the fewest
+// instructions per keypoint and is the throughput kernel; one keypoint per wavefront has the
+// shorter critical path (a wavefront walks the levels of one keypoint, not three) and wins when
+// all keypoints of a call fit on the device at once, i.e. for single-frame, latency-bound calls.
+// VO_KLT_VARIANT=1 or =3 in the environment forces one of them (comparison runs, parity tests).
+#define KLT_ONE_PER_WAVE_MAX 8192     // 1024 SIMDs x 8 wavefronts
+static int klt_variant(int64_t keypoints)
 {
     const char *e = getenv("VO_KLT_VARIANT");
-    return (e && e[0] == '1') ? 1 : 3;
+    if (e && e[0] == '1') return 1;
+    if (e && e[0] == '3') return 3;
+    return keypoints <= KLT_ONE_PER_WAVE_MAX ? 1 : 3;
 }
 
 static int launch_klt(vo_ctx *ctx, KltArgs &a)
 {
-    if (klt_variant() == 3) {
+    if (klt_variant((int64_t)a.n * a.batch) == 3) {
         a.blocks_per_image = (a.n + K3_KP_BLOCK - 1) / K3_KP_BLOCK;
         VO_REQUIRE((int64_t)a.n * a.batch < (1ll << 30), "vo_klt_track: too many keypoints (%lld)", (long long)a.n * a.batch);
         int64_t blocks3 = (int64_t)a.blocks_per_image * a.batch;
