@@ -378,7 +378,7 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 // system by Cholesky.  Stops when the cost rises (the previous pose is returned), stops
 // improving by more than 1e-10 relative, or after max_iters.
 // ---------------------------------------------------------------------------
-#define REFINE_THREADS 1024
+#define REFINE_THREADS 512
 struct Pose6 { double v[6]; };
 
 __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float *__restrict__ X, const float *__restrict__ x,
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
             int stop = 0;
             if (!(cost == cost) || fabs(cost) == __builtin_inf() || cost > prev_cost * (1 + 1e-12)) {
                 // diverged: fall back to the pose before the last step
+#pragma unroll
                 for (int k = 0; k < 6; ++k) cam[k] = prev_cam[k];
                 stop = 1;
             } else {
@@ -437,42 +438,62 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                 if (it == max_iters || (prev_cost < __builtin_inf() && prev_cost - cost < 1e-10 * fmax(cost, 1e-300))) stop = 1;
             }
             if (!stop) {
+                // every loop below has constant bounds and is fully unrolled, so the 6x6 system lives in
+                // registers (indexed through run-time loops it went to scratch memory, and the solve
+                // of one lane dominated the iteration)
                 double A[6][6], g[6];
-                int e = 0;
                 double tr = 0;
-                for (int a = 0; a < 6; ++a)
-                    for (int b = a; b < 6; ++b) { A[a][b] = tot[e]; A[b][a] = tot[e]; ++e; }
+                {
+                    int e = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int b = a; b < 6; ++b) { A[a][b] = tot[e]; A[b][a] = tot[e]; ++e; }
+                }
+#pragma unroll
                 for (int a = 0; a < 6; ++a) { tr += A[a][a]; g[a] = -tot[21 + a]; }
+#pragma unroll
                 for (int a = 0; a < 6; ++a) A[a][a] += 1e-9 * tr / 6;
                 bool ok = true;
-                for (int k = 0; k < 6 && ok; ++k) {       // Cholesky, lower triangle in place
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {       // Cholesky, lower triangle in place
                     double d = A[k][k];
+#pragma unroll
                     for (int m = 0; m < k; ++m) d -= A[k][m] * A[k][m];
-                    if (!(d > 0)) { ok = false; break; }
-                    A[k][k] = sqrt(d);
+                    ok = ok && d > 0;
+                    const double piv = sqrt(ok ? d : 1.0);
+                    A[k][k] = piv;
+#pragma unroll
                     for (int i = k + 1; i < 6; ++i) {
                         double v = A[i][k];
+#pragma unroll
                         for (int m = 0; m < k; ++m) v -= A[i][m] * A[k][m];
-                        A[i][k] = v / A[k][k];
+                        A[i][k] = v / piv;
                     }
                 }
                 if (!ok) stop = 1;
                 else {
+#pragma unroll
                     for (int k = 0; k < 6; ++k) {
                         double v = g[k];
+#pragma unroll
                         for (int m = 0; m < k; ++m) v -= A[k][m] * g[m];
                         g[k] = v / A[k][k];
                     }
+#pragma unroll
                     for (int k = 5; k >= 0; --k) {
                         double v = g[k];
+#pragma unroll
                         for (int m = k + 1; m < 6; ++m) v -= A[m][k] * g[m];
                         g[k] = v / A[k][k];
                     }
                     prev_cost = cost;
+#pragma unroll
                     for (int k = 0; k < 6; ++k) { prev_cam[k] = cam[k]; cam[k] += g[k]; }
                     iters_done = it + 1;
                 }
             }
+#pragma unroll
             for (int k = 0; k < 6; ++k) cam_s[k] = cam[k];
             stop_s = stop;
         }
@@ -483,6 +504,7 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
         __syncthreads();
     }
     if (tid == 0) {
+#pragma unroll
         for (int k = 0; k < 6; ++k) out[k] = cam[k];
         out[6] = last_cost;
         out[7] = (double)iters_done;
