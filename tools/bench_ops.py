@@ -66,6 +66,23 @@ def main():
                                  "frac": nbytes / (ms * 1e-3) / 1e9 / HBM},
                     "cpu_oracle_ms": cms, "cpu_cores": 1})
 
+    # whole RANSAC calls at the same sizes: 2048 samples drawn, solved and scored, OpenCV's loop replayed
+    # (a high confidence keeps the adaptive count at the maximum), winner's mask, PnP refit; synchronous
+    for name, fn in [
+        ("find_fundamental_ransac", lambda: hip.find_fundamental_ransac(ctx, sc["m1"], sc["m2"], 0.5, 1.0, H)),
+        ("solve_pnp_ransac (host points)", lambda: hip.solve_pnp_ransac(ctx, sc["X"], sc["m2"], sc["K"], 1.0, 1.0, H)),
+        ("solve_pnp_ransac (device points)", lambda: hip.solve_pnp_ransac(ctx, X, m2, sc["K"], 1.0, 1.0, H)),
+    ]:
+        for _ in range(3):
+            res = fn()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            res = fn()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        out.append({"op": name, "workload": f"whole call: {n} correspondences, {H} samples (up to {3 * H if 'fund' in name else H} "
+                    "candidates), host wall time", "ms": ms, "inliers": res[2],
+                    "candidate_evals_per_s": n * H / (ms * 1e-3)})
+
     # ---- config 4: BA normal equations --------------------------------------
     pb = synth.ba_problem(F=10, P=5000, seed=0)
     F, P = pb["F"], pb["P"]
