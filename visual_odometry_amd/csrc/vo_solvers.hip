@@ -217,9 +217,17 @@ __global__ __launch_bounds__(SOLVER_THREADS) void seven_point_kernel(const float
                                                                     int n, const int *__restrict__ subsets, int S,
                                                                     double *__restrict__ F, int *__restrict__ nsol)
 {
+    // The elimination swaps rows and columns chosen at run time, so the 7x9 system cannot live in
+    // registers; it is kept in LDS, one 63-double column per lane (odd stride: lanes touching the
+    // same element hit different banks), not in scratch memory, whose latency dominated the kernel.
+    // The same holds for the column permutation and the two null-space vectors (scattered through it).
+    __shared__ double A_lds[SOLVER_THREADS][63 + 18];
+    __shared__ int perm_lds[SOLVER_THREADS][9];
     const int s = blockIdx.x * SOLVER_THREADS + threadIdx.x;
     if (s >= S) return;
-    double A[7][9];
+    double(*A)[9] = reinterpret_cast<double(*)[9]>(A_lds[threadIdx.x]);
+    double *f1 = A_lds[threadIdx.x] + 63, *f2 = f1 + 9;
+    int *perm = perm_lds[threadIdx.x];
     bool ok = true;
     for (int k = 0; k < 7; ++k) {
         const int id = subsets[7 * s + k];
@@ -232,7 +240,6 @@ __global__ __launch_bounds__(SOLVER_THREADS) void seven_point_kernel(const float
         A[k][6] = x1; A[k][7] = y1; A[k][8] = 1.0;
     }
     // Gauss-Jordan with complete pivoting; perm[c] = original column at position c
-    int perm[9];
     for (int c = 0; c < 9; ++c) perm[c] = c;
     for (int r = 0; r < 7 && ok; ++r) {
         int pr = r, pc = r;
@@ -253,11 +260,9 @@ __global__ __launch_bounds__(SOLVER_THREADS) void seven_point_kernel(const float
         }
     }
     int count = 0;
-    double out[27];
-    for (int k = 0; k < 27; ++k) out[k] = 0.0;
+    double *out = F + 27 * (int64_t)s;
     if (ok) {
         // null-space basis: free columns 7 and 8 of the permuted system
-        double f1[9], f2[9];
         for (int c = 0; c < 9; ++c) { f1[c] = 0; f2[c] = 0; }
         for (int r = 0; r < 7; ++r) { f1[perm[r]] = -A[r][7]; f2[perm[r]] = -A[r][8]; }
         f1[perm[7]] = 1.0; f2[perm[8]] = 1.0;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(SOLVER_THREADS) void seven_point_kernel(const float
             ++count;
         }
     }
-    for (int k = 0; k < 27; ++k) F[27 * (int64_t)s + k] = out[k];
+    for (int k = 9 * count; k < 27; ++k) out[k] = 0.0;      // unused solution slots
     nsol[s] = count;
 }
 
