@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams-per-gpu", type=int, default=64)
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="strong scaling: this many streams in all, divided over the GPUs (must divide evenly); "
+                         "default 0 = weak scaling with --streams-per-gpu streams on every GPU")
     ap.add_argument("--ring", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -133,6 +136,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.total_streams:
+        if args.total_streams % world:
+            raise SystemExit(f"--total-streams {args.total_streams} does not divide over {world} GPUs")
+        args.streams_per_gpu = args.total_streams // world
     S, R = args.streams_per_gpu, args.ring
     owned = streams.shard_streams(S * world, rank, world)      # weak scaling: S streams per GPU
     if args.distinct and args.distinct < S:
@@ -227,7 +234,7 @@ def main():
         res = {
             "metric": "tracked frames/s (KITTI 1241x376, 2k kp)", "value": fps, "unit": "frames/s",
             "keypoints_per_s": fps * N_KP, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "u8 images, int32 fixed-point bilinear, f32 normal equations",
             "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 u8 frames, 2000 keypoints/frame, 4-level pyramid "
