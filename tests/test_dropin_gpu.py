@@ -188,3 +188,24 @@ def test_two_view_geometry_matches_reference(ctx):
     assert hip.triangulate(ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), d["M1"], d["M2"]).shape == (0, 4)
     with pytest.raises(ValueError):
         hip.triangulate(ctx, d["p1"], d["p2"][:-1], d["M1"], d["M2"])
+
+
+def test_klt_pyramid_reuse_is_transparent(ctx):
+    """reuse_pyramids keeps the previous call's next-frame pyramid only for the identical array object;
+    results equal the rebuild-everything path, and a different or modified-then-copied frame is rebuilt."""
+    from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation
+    f = [synth.frame_pair((240, 320), seed=s)[0] for s in (1, 2, 3)]
+    f[1] = synth.frame_pair((240, 320), seed=1)[1]
+    f[2] = np.roll(f[1], 2, axis=1)
+    pts = synth.uniform_keypoints((240, 320), 300, seed=4, margin=25)
+    plain = [PoseEstimation.KLT(f[i], f[i + 1], pts) for i in range(2)]
+    chained = [PoseEstimation.KLT(f[i], f[i + 1], pts, reuse_pyramids=True) for i in range(2)]   # second call reuses f[1]
+    for (a, sa), (b, sb) in zip(plain, chained):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(sa, sb)
+    # an equal copy is another object: rebuilt, same answer; so is a frame whose predecessor was something else
+    c, sc = PoseEstimation.KLT(f[1].copy(), f[2], pts, reuse_pyramids=True)
+    np.testing.assert_array_equal(c, plain[1][0])
+    d, sd = PoseEstimation.KLT(f[0], f[1], pts, reuse_pyramids=True)
+    np.testing.assert_array_equal(d, plain[0][0])
+    np.testing.assert_array_equal(sd, plain[0][1])

@@ -1,5 +1,6 @@
 """Shared GPU context and pyramid cache of the drop-in classes."""
-from typing import Dict, Tuple
+import weakref
+from typing import Dict, Optional, Tuple
 
 from .. import hip
 
@@ -17,3 +18,30 @@ def pyramid_pair(h: int, w: int, max_level: int, win: int = 21, device: int = 0)
         ctx = context(device)
         _pyr_cache[key] = [hip.Pyramid(ctx, 1, h, w, max_level, win) for _ in range(2)]
     return _pyr_cache[key]
+
+
+# (device, h, w, max_level, win) -> (weak reference to the image whose pyramid sits in slot i, i)
+_last_next: Dict[Tuple[int, int, int, int, int], Tuple["weakref.ref", int]] = {}
+
+
+def pyramids_for_pair(img0, img1, max_level: int, win: int = 21, device: int = 0, reuse: bool = False):
+    """Built pyramids (prev, next) of two frames of one size.  With reuse, a frame that is the very
+    array object given as `img1` in the previous call keeps the pyramid built for it then (the caller
+    vouches that it has not been written to since): only the new frame is uploaded and filtered."""
+    h, w = img0.shape
+    key = (device, h, w, max_level, win)
+    pair = pyramid_pair(h, w, max_level, win, device)
+    slot: Optional[int] = None
+    if reuse and key in _last_next:
+        ref, i = _last_next[key]
+        if ref() is img0:
+            slot = i
+    if slot is None:
+        slot = 0
+        pair[0].build(img0)
+    pair[1 - slot].build(img1)
+    try:
+        _last_next[key] = (weakref.ref(img1), 1 - slot)
+    except TypeError:           # not weak-referenceable (not an ndarray): nothing to remember
+        _last_next.pop(key, None)
+    return pair[slot], pair[1 - slot]

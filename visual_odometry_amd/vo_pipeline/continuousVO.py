@@ -178,7 +178,8 @@ class ContinuousVO:
         prev_img = self.frame_queue.get_head().img
         prev_keypoints, prev_trajectories, prev_landmarks = store.at_frame(store.latest_frame)
 
-        tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints)
+        # the queue's images are never written to: the pyramid built for prev_img one step ago is kept
+        tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints, reuse_pyramids=True)
         tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
                                                                       prev_trajectories)
         if tracked_landmarks.shape[0] > 5:

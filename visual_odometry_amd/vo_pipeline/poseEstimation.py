@@ -68,20 +68,25 @@ class PoseEstimation:
         return pts1
 
     @staticmethod
-    def KLT(img0: np.ndarray, img1: np.ndarray, prev_kpts: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """Pyramidal LK from img0 to img1 -> (tracked_pts (N,2) float32, status (N,1) uint8)."""
-        img0 = np.ascontiguousarray(img0, dtype=np.uint8)
-        img1 = np.ascontiguousarray(img1, dtype=np.uint8)
-        if img0.ndim != 2 or img0.shape != img1.shape:
+    def KLT(img0: np.ndarray, img1: np.ndarray, prev_kpts: np.ndarray,
+            reuse_pyramids: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """Pyramidal LK from img0 to img1 -> (tracked_pts (N,2) float32, status (N,1) uint8).
+
+        reuse_pyramids (not in the reference, off by default): when img0 is the same array object that was
+        img1 of the previous call and the caller has not written to it since, its pyramid is kept instead of
+        being uploaded and rebuilt -- what a frame loop that tracks frame t-1 -> t, then t -> t+1 wants."""
+        a0 = np.ascontiguousarray(img0, dtype=np.uint8)
+        a1 = np.ascontiguousarray(img1, dtype=np.uint8)
+        if a0.ndim != 2 or a0.shape != a1.shape:
             raise ValueError("KLT: img0 and img1 must be grayscale images of one size")
         pts = np.float32(prev_kpts).reshape(-1, 2)
         n = pts.shape[0]
         if n == 0:
             return np.zeros((0, 2), np.float32), np.zeros((0, 1), np.uint8)
         ctx = _runtime.context()
-        p0, p1 = _runtime.pyramid_pair(img0.shape[0], img0.shape[1], params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS)
-        p0.build(img0)
-        p1.build(img1)
+        # conversions above return the caller's own object when it already is contiguous uint8, so
+        # object identity carries over from call to call
+        p0, p1 = _runtime.pyramids_for_pair(a0, a1, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS, reuse=reuse_pyramids)
         out, st, _ = hip.klt_track(ctx, p0, p1, pts, max_iters=params.KLT_N_ITERS, eps=0.001,
                                    min_eig=params.KLT_MIN_EIGEN_THRESHOLD)
         return out[0], st[0].reshape(n, 1)
