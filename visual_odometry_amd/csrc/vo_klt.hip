@@ -480,9 +480,18 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
     asm volatile("" : "+v"(bias));   // keep the rounding constant in one register
     uint32_t sh14 = 14;
     asm volatile("" : "+v"(sh14));
-    uint32_t cm = 0xffffffffu;
-    if (MASKED)
-        cm = ((unsigned)(ipx + col) < (unsigned)w ? 0xffffu : 0u) | ((unsigned)(ipx + col + 1) < (unsigned)w ? 0xffff0000u : 0u);
+    // MASKED: derivatives outside the image count as zero.  Columns: a derivative pair {d[x], d[x+1]} only ever
+    // meets the weight pair it is multiplied with, so the column test is folded into the weights once.  Rows:
+    // bit k of rowbits says whether derivative row k lies inside the image; a signed one-bit field extract
+    // turns it into an all-ones / zero mask.
+    uint32_t rowbits = 0;
+    if (MASKED) {
+        const uint32_t cm = ((unsigned)(ipx + col) < (unsigned)w ? 0xffffu : 0u) | ((unsigned)(ipx + col + 1) < (unsigned)w ? 0xffff0000u : 0u);
+        wtd &= cm;
+        wbd &= cm;
+        const int lo = min(max(-ipy, 0), 22), hi = min(max(h - ipy, 0), 22);     // rows lo .. hi-1 are inside
+        rowbits = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    }
     a11 = 0; a12 = 0; a22 = 0;
 #pragma unroll
     for (int r = 0; r < 24; ++r) {
@@ -495,7 +504,7 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
             uint32_t dx = __builtin_bit_cast(uint32_t, (s16x2)((h0a + h0c) * (short)3 + h0b * (short)10));
             uint32_t dy = __builtin_bit_cast(uint32_t, (s16x2)(h1c - h1a));
             if (MASKED) {
-                const uint32_t m = (unsigned)(ipy + k) < (unsigned)h ? cm : 0u;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits, k, 1);
                 dx &= m;
                 dy &= m;
             }
