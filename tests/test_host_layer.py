@@ -167,3 +167,25 @@ def test_numpy_solvers_on_planted_geometry():
     assert sols
     err = min(np.abs(R - sc["R"]).max() + np.abs(t - sc["t"]).max() for R, t in sols)
     assert err < 1e-3
+
+
+def test_reference_module_names_resolve_to_the_mirror():
+    """A script written against the reference imports `vo_pipeline.*`, `utils.*` and `params`."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import visual_odometry_amd as v; v.install_reference_names();"
+            "from vo_pipeline.poseEstimation import PoseEstimation, AlgoMethod;"
+            "from vo_pipeline.trackPoints import TrackPoints;"
+            "from vo_pipeline.featureExtraction import FeatureExtractor, ExtractorType;"
+            "from vo_pipeline.bootstrap import BootstrapInitializer;"
+            "from vo_pipeline.bundleAdjustment import BundleAdjustment;"
+            "from vo_pipeline.poseOptimization import PoseGraphOptimizer;"
+            "from vo_pipeline.continuousVO import ContinuousVO;"
+            "from vo_pipeline.keypointTrajectory import KeypointTrajectories;"
+            "from vo_pipeline.frameState import FrameState;"
+            "from utils.frameQueue import FrameQueue; from utils.matrix import hom_inv; from utils.loadData import Dataset;"
+            "import params; assert params.KLT_RADIUS == 21;"
+            "import visual_odometry_amd.vo_pipeline.poseEstimation as m; assert m.PoseEstimation is PoseEstimation; print('ok')"
+            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
