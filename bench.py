@@ -100,8 +100,8 @@ def cpu_baseline(frames, pts, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams-per-gpu", type=int, default=64)
     ap.add_argument("--total-streams", type=int, default=0,
                     help="strong scaling: this many streams in all, divided over the GPUs (must divide evenly); "
