@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed steps are run for this long before the warmup steps (clock ramp)")
     ap.add_argument("--streams-per-gpu", type=int, default=64)
     ap.add_argument("--total-streams", type=int, default=0,
                     help="strong scaling: this many streams in all, divided over the GPUs (must divide evenly); "
@@ -199,6 +201,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the GPU's clocks take ~50 ms of load to settle: run untimed steps for a fixed wall time first,
+    # so that short timed regions measure the same sustained state as long ones
+    t_settle = time.perf_counter() + args.settle_ms * 1e-3
+    while time.perf_counter() < t_settle:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     EV_EVERY = 4
@@ -239,7 +248,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 u8 frames, 2000 keypoints/frame, 4-level pyramid "
                                    "(maxLevel=3), win 21, 10 iters, eps 1e-3, minEig 1e-2",
-                       "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R,
+                       "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R, "settle_ms": args.settle_ms,
                        "schedule": "one stream" if args.no_pipeline else "pyramid of frame k+2 on a second HIP stream during tracker k",
                        "distinct_streams": (args.distinct if args.distinct and args.distinct < S else S) * world,
                        "tracked_fraction": tracked_frac, "parallelism": f"stream-parallel x{world}"},

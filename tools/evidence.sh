@@ -15,5 +15,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1 || { echo stats failed; tail -20 $O/stats.log; exit 1; }
 cd $R
 # counters are device-wide: one stream, so that no other kernel runs beside the one being counted
-bash tools/pmc_passes.sh $O/pmc --steps 3 --warmup 1 --no-pipeline || exit 1
+bash tools/pmc_passes.sh $O/pmc --steps 3 --warmup 1 --settle-ms 0 --no-pipeline || exit 1
 echo evidence done
