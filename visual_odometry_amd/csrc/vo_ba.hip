@@ -161,9 +161,11 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
         rr[0] = qnan;
     }
     // cost: wave sum, one atomic per wave
-    double cs = wave_sum_d(rr[0] * rr[0] + rr[1] * rr[1]);
-    if (lane == 63) unsafeAtomicAdd(cost, 0.5 * cs);
-    if (!WITH_J) return;
+    const double cs = wave_sum_d(rr[0] * rr[0] + rr[1] * rr[1]);
+    if (!WITH_J) {
+        if (lane == 63) unsafeAtomicAdd(cost, 0.5 * cs);
+        return;
+    }
 
     if (!active) {
 #pragma unroll
@@ -171,6 +173,70 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
 #pragma unroll
         for (int k = 0; k < 6; ++k) Jp[k] = 0;
     }
+    // camera blocks: when every active lane of the wave sees one camera, reduce over the
+    // wave first (the caller's observations are sorted by camera).  The sums go to one of
+    // BA_REPLICAS copies of the camera blocks chosen by workgroup, so that the float64
+    // atomics of the many waves of one camera do not queue on the same few cache lines;
+    // ba_cam_sum_kernel adds the copies up.
+    // (this section comes before the global stores and atomics of the wave: its wavefront fence waits for
+    // every outstanding memory operation of the wave, and behind those writes it cost 25 us of 60 at one window)
+    const unsigned long long act = __ballot(active);
+    if (act != 0) {
+        double *rep = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42;
+        const int first = __ffsll((long long)act) - 1;
+        const long long c0 = __shfl((long long)c, first);
+        const bool uniform_cam = __ballot(active && c != c0) == 0;
+        if (uniform_cam) {
+            // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r: every lane parks its 27 terms in
+            // LDS (row per term, column per lane), 54 lanes each add up half a row, one shuffle joins
+            // the halves, and 27 lanes issue the atomics (mirroring the off-diagonal entries).
+            if constexpr (WITH_J) {
+                __shared__ double red[BA_THREADS / 64][27][65];
+                double(*mine)[65] = red[threadIdx.x >> 6];
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) mine[e++][lane] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) mine[21 + a][lane] = Jc[a] * rr[0] + Jc[6 + a] * rr[1];
+                // the rows are read by other lanes of the same wavefront: only the LDS writes have to have
+                // landed (a wavefront-scope fence would also wait for the wave's global stores)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int v = lane % 27, half = lane / 27;   // lanes 54..63 repeat rows 0..9 (third "half" is ignored)
+                const double *row = &mine[v][(half & 1) * 32];
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                for (int i = 0; i < 32; i += 4) { s0 += row[i]; s1 += row[i + 1]; s2 += row[i + 2]; s3 += row[i + 3]; }
+                const double part = (s0 + s1) + (s2 + s3);
+                const double other = __shfl_down(part, 27);
+                if (lane < 27) {
+                    const double tot = part + other;
+                    double *hc = rep + 42 * c0;
+                    // term index -> (a, b) of the upper triangle, row-major
+                    const int ta = lane < 6 ? 0 : lane < 11 ? 1 : lane < 15 ? 2 : lane < 18 ? 3 : lane < 20 ? 4 : 5;
+                    const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
+                    if (lane < 21) {
+                        const int tb = ta + (lane - first_of_row);
+                        unsafeAtomicAdd(hc + ta * 6 + tb, tot);
+                        if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, tot);
+                    } else {
+                        unsafeAtomicAdd(hc + 36 + (lane - 21), tot);
+                    }
+                }
+            }
+        } else if (active) {
+            double *hc = rep + 42 * c;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = 0; b < 6; ++b) unsafeAtomicAdd(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+                unsafeAtomicAdd(hc + 36 + a, Jc[a] * rr[0] + Jc[6 + a] * rr[1]);
+            }
+        }
+    }
+
     if (valid) {
         double *hx = Hcp + 18 * (int64_t)i;
 #pragma unroll
@@ -193,65 +259,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
             unsafeAtomicAdd(gp + a, Jp[a] * rr[0] + Jp[3 + a] * rr[1]);
         }
     }
-    // camera blocks: when every active lane of the wave sees one camera, reduce over the
-    // wave first (the caller's observations are sorted by camera).  The sums go to one of
-    // BA_REPLICAS copies of the camera blocks chosen by workgroup, so that the float64
-    // atomics of the many waves of one camera do not queue on the same few cache lines;
-    // ba_cam_sum_kernel adds the copies up.
-    const unsigned long long act = __ballot(active);
-    if (act == 0) return;
-    double *rep = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42;
-    const int first = __ffsll((long long)act) - 1;
-    const long long c0 = __shfl((long long)c, first);
-    const bool uniform_cam = __ballot(active && c != c0) == 0;
-    if (uniform_cam) {
-        // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r: every lane parks its 27 terms in
-        // LDS (row per term, column per lane), 54 lanes each add up half a row, one shuffle joins
-        // the halves, and 27 lanes issue the atomics (mirroring the off-diagonal entries).
-        if constexpr (WITH_J) {
-            __shared__ double red[BA_THREADS / 64][27][65];
-            double(*mine)[65] = red[threadIdx.x >> 6];
-            int e = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) mine[e++][lane] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) mine[21 + a][lane] = Jc[a] * rr[0] + Jc[6 + a] * rr[1];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int v = lane % 27, half = lane / 27;   // lanes 54..63 repeat rows 0..9 (third "half" is ignored)
-            const double *row = &mine[v][(half & 1) * 32];
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-            for (int i = 0; i < 32; i += 4) { s0 += row[i]; s1 += row[i + 1]; s2 += row[i + 2]; s3 += row[i + 3]; }
-            const double part = (s0 + s1) + (s2 + s3);
-            const double other = __shfl_down(part, 27);
-            if (lane < 27) {
-                const double tot = part + other;
-                double *hc = rep + 42 * c0;
-                // term index -> (a, b) of the upper triangle, row-major
-                const int ta = lane < 6 ? 0 : lane < 11 ? 1 : lane < 15 ? 2 : lane < 18 ? 3 : lane < 20 ? 4 : 5;
-                const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
-                if (lane < 21) {
-                    const int tb = ta + (lane - first_of_row);
-                    unsafeAtomicAdd(hc + ta * 6 + tb, tot);
-                    if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, tot);
-                } else {
-                    unsafeAtomicAdd(hc + 36 + (lane - 21), tot);
-                }
-            }
-        }
-    } else if (active) {
-        double *hc = rep + 42 * c;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int b = 0; b < 6; ++b) unsafeAtomicAdd(hc + a * 6 + b, Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-            unsafeAtomicAdd(hc + 36 + a, Jc[a] * rr[0] + Jc[6 + a] * rr[1]);
-        }
-    }
+    if (lane == 63) unsafeAtomicAdd(cost, 0.5 * cs);
 }
 
 // Hcc[c] and g[6c..6c+5] = sum over the replicas filled by ba_kernel (overwrites both); with
