@@ -269,6 +269,22 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, in
                                int max_iters, uint64_t *rng_state, double *F_out, uint8_t *inlier_mask,
                                int32_t *n_inliers);
 
+/* ---- descriptor matching -----------------------------------------------------------------
+ * vo_knn_match2 replaces matcher.knnMatch(des1, des2, k=2) inside
+ * FeatureMatcher.match_descriptors (vo_pipeline/featureMatching.py:52-63) and the ratio test
+ * of FeatureMatcher.match_filter (featureMatching.py:65-69).  The search is exhaustive: the
+ * result of cv.BFMatcher() (featureMatching.py:45), which the FLANN kd-tree matcher of
+ * featureMatching.py:46-50 approximates.  des1 (n1,dim) and des2 (n2,dim) float32, row-major,
+ * dim = 128 (device pointers 16-byte aligned).  Per query row q: idx[q] = the two train rows with the smallest
+ * float32 L2 distance sqrtf(sum_k (a_k-b_k)^2), nearest first, equal distances to the lower
+ * row; dist[q] = those distances; keep[q] (may be NULL) = dist[q][0] < ratio * dist[q][1],
+ * evaluated in double as the reference's Python expression is.  A missing neighbour (n2 < 2)
+ * is index -1 at distance +inf and fails the ratio test.  idx (n1,2) int32, dist (n1,2)
+ * float32, keep (n1) uint8 follow `mem`.
+ */
+int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float *des2, int n2, int dim, double ratio,
+                  int32_t *idx, float *dist, uint8_t *keep, int mem);
+
 #ifdef __cplusplus
 }
 #endif

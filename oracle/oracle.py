@@ -32,6 +32,7 @@ def lib():
         _declare(_lib)
         _declare_more(_lib)
         _declare_harris(_lib)
+        _declare_match(_lib)
     return _lib
 
 
@@ -78,6 +79,11 @@ def _declare_harris(L):
     L.vo_or_harris_response.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _f32p]
     L.vo_or_nms_topk.restype = ctypes.c_int
     L.vo_or_nms_topk.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _f32p, _f32p]
+
+
+def _declare_match(L):
+    L.vo_or_knn_match2.restype = None
+    L.vo_or_knn_match2.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_double, _i32p, _f32p, _u8p]
 
 
 def _p(a, t):
@@ -216,3 +222,17 @@ def nms_topk(R, K, rel_thresh=0.01, radius=1):
     xy = np.zeros((K, 2), np.float32); sc = np.zeros(K, np.float32)
     m = lib().vo_or_nms_topk(_p(R, _f32p), w, h, float(rel_thresh), int(radius), int(K), _p(xy, _f32p), _p(sc, _f32p))
     return xy, sc, m
+
+
+def knn_match2(des1, des2, ratio=0.8):
+    """Two nearest train rows per query row: (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8)."""
+    a = np.ascontiguousarray(des1, np.float32)
+    b = np.ascontiguousarray(des2, np.float32)
+    n1, n2 = a.shape[0], b.shape[0]
+    dim = a.shape[1] if a.ndim == 2 else b.shape[1]
+    idx = np.full((n1, 2), -1, np.int32)
+    dist = np.full((n1, 2), np.inf, np.float32)
+    keep = np.zeros(n1, np.uint8)
+    lib().vo_or_knn_match2(_p(a, _f32p), n1, _p(b, _f32p), n2, int(dim), float(ratio), _p(idx, _i32p), _p(dist, _f32p),
+                           _p(keep, _u8p))
+    return idx, dist, keep

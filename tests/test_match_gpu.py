@@ -1,0 +1,104 @@
+"""vo_knn_match2 (through the C-ABI) against the CPU oracle: bit-exact indices, distances and ratio mask
+on byte-valued (SIFT-shaped) descriptors, which take the matrix-core kernel, and on general float
+descriptors, which take the float kernel; both kernels agree on byte-valued input."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, d1, d2, ratio=0.8):
+    from visual_odometry_amd import hip
+    idx, dist, keep = hip.knn_match2(ctx, d1, d2, ratio)
+    ri, rd, rk = oracle.knn_match2(d1, d2, ratio)
+    assert idx.dtype == np.int32 and dist.dtype == np.float32 and keep.dtype == np.uint8
+    assert (idx == ri).all()
+    assert (dist.view(np.uint32) == rd.view(np.uint32)).all()
+    assert (keep == rk).all()
+    return idx, dist, keep
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 2), (31, 33), (64, 64), (127, 129), (300, 1000), (1000, 257), (2000, 2000)])
+def test_byte_descriptors_bit_exact(ctx, oracle, n1, n2):
+    d1, d2, truth = synth.sift_like_descriptors(n1, n2, seed=n1 + n2)
+    idx, _, keep = _check(ctx, oracle, d1, d2)
+    if n1 >= 300:
+        hit = truth >= 0
+        assert (idx[hit, 0] == truth[hit]).mean() > 0.95 and keep[hit].mean() > 0.9
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 3), (65, 130), (500, 777), (1500, 1500)])
+def test_float_descriptors_bit_exact(ctx, oracle, n1, n2):
+    rng = np.random.default_rng(n1 * 7 + n2)
+    d1 = rng.normal(0, 50, (n1, 128)).astype(np.float32)
+    d2 = rng.normal(0, 50, (n2, 128)).astype(np.float32)
+    _check(ctx, oracle, d1, d2, 0.9)
+
+
+def test_extreme_bytes_and_ties(ctx, oracle):
+    # all-255 against all-0 rows is the largest sum the matrix-core path has to hold exactly (2^23.99)
+    d1 = np.full((3, 128), 255, np.float32)
+    d2 = np.zeros((70, 128), np.float32)
+    d2[40] = 255
+    d2[7] = 255            # equal distance: the lower row comes first
+    d2[50, :64] = 255
+    idx, dist, _ = _check(ctx, oracle, d1, d2)
+    assert idx[0].tolist() == [7, 40] and dist[0].tolist() == [0.0, 0.0]
+    d1[1] = 0
+    idx, dist, _ = _check(ctx, oracle, d1, d2)
+    assert idx[1].tolist() == [0, 1]
+    # one non-integer entry anywhere sends the whole call down the float path, same answers
+    d2[69, 127] = 0.5
+    _check(ctx, oracle, d1, d2)
+    d2[69, 127] = 256.0
+    _check(ctx, oracle, d1, d2)
+    d2[69, 127] = -1.0
+    _check(ctx, oracle, d1, d2)
+
+
+def test_missing_neighbours_and_empty_sets(ctx, oracle):
+    from visual_odometry_amd import hip
+    d1, d2, _ = synth.sift_like_descriptors(10, 5, seed=2)
+    idx, dist, keep = _check(ctx, oracle, d1, d2[:1])
+    assert (idx[:, 1] == -1).all() and np.isinf(dist[:, 1]).all() and not keep.any()
+    idx, dist, keep = _check(ctx, oracle, d1, d2[:0])
+    assert (idx == -1).all() and np.isinf(dist).all()
+    idx, dist, keep = hip.knn_match2(ctx, d1[:0], d2)
+    assert idx.shape == (0, 2) and dist.shape == (0, 2) and keep.shape == (0,)
+    with pytest.raises(Exception):
+        hip.knn_match2(ctx, np.zeros((4, 64), np.float32), np.zeros((4, 64), np.float32))
+
+
+def test_device_resident_call(ctx, oracle):
+    import torch
+    from visual_odometry_amd import hip
+    d1, d2, _ = synth.sift_like_descriptors(3000, 3000, seed=9)
+    tctx = hip.Context.from_torch(0)
+    a, b = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    idx, dist, keep = hip.knn_match2(tctx, a, b, 0.8)
+    idx2, dist2, keep2 = hip.knn_match2(tctx, a[:100], b[:50], 0.8)     # smaller call reuses the buffers
+    tctx.sync()
+    ri, rd, rk = oracle.knn_match2(d1, d2, 0.8)
+    assert (idx.cpu().numpy() == ri).all() and (dist.cpu().numpy() == rd).all() and (keep.cpu().numpy() == rk).all()
+    ri, rd, rk = oracle.knn_match2(d1[:100], d2[:50], 0.8)
+    assert (idx2.cpu().numpy() == ri).all() and (dist2.cpu().numpy() == rd).all() and (keep2.cpu().numpy() == rk).all()
+
+
+def test_feature_matcher_mirror(ctx, oracle):
+    from visual_odometry_amd.vo_pipeline.featureMatching import FeatureMatcher, MatcherType
+    d1, d2, truth = synth.sift_like_descriptors(400, 500, seed=4)
+    ri, rd, rk = oracle.knn_match2(d1, d2, 0.8)
+    for mt in (MatcherType.BF, MatcherType.FLANN):
+        m = FeatureMatcher(mt, k=2, matching_threshold=0.8)
+        good = m.match_descriptors(d1, d2)
+        rows = np.nonzero(rk)[0]
+        assert [g.queryIdx for g in good] == rows.tolist()
+        assert [g.trainIdx for g in good] == ri[rows, 0].tolist()
+        assert [g.distance for g in good] == [float(x) for x in rd[rows, 0]]
+        every = m.match_descriptors(d1, d2, filter=False)
+        assert len(every) == 400 and [g.trainIdx for g in every] == ri[:, 0].tolist()
+    # the reference's own filter generator works on pairs of these objects
+    pairs = [(g, g) for g in every[:3]]
+    assert list(m.match_filter(pairs)) == []

@@ -81,6 +81,8 @@ SIGNATURES = {
                                                   ctypes.POINTER(ctypes.c_int32)]),
     "vo_refine_pose": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p,
                                       ctypes.c_int]),
+    "vo_knn_match2": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp, c_vp,
+                                     c_vp, ctypes.c_int]),
 }
 
 _lib = None

@@ -1,0 +1,291 @@
+// Brute-force two-nearest-neighbour matching of 128-dimensional descriptors.
+//
+// Replaces FeatureMatcher.match_descriptors -> matcher.knnMatch(des1, des2, k=2)
+// (vo_pipeline/featureMatching.py:52-63; exact search, i.e. what cv.BFMatcher()
+// of featureMatching.py:45 returns and what the FLANN kd-trees of :46-50
+// approximate) and the ratio test of match_filter (featureMatching.py:65-69).
+// Distance of a pair = sqrtf(sum_k (a_k - b_k)^2), the float32 NORM_L2 of
+// BFMatcher; equal distances go to the lower train index.
+//
+// Two kernels produce the same candidate keys {float bits of the squared distance,
+// train index} and only one of them does work in a call:
+//  * knn2_mfma_kernel -- descriptors whose entries are integers in [0, 255] (what
+//    SIFT emits: float32 holding saturated bytes).  Such values are exact in bf16,
+//    their products and the 128-term sums are exact in float32 (< 2^24), so
+//    |a|^2 + |b|^2 - 2 a.b from the matrix cores equals the direct sum bit for bit.
+//  * knn2_f32_kernel -- anything else: direct differences, one fused multiply-add
+//    per term in ascending k, the summation order of the CPU checker.
+// desc_pack_kernel decides which: it converts both sets to bf16, takes the norms
+// and raises a device flag at the first entry that is not such an integer.
+#include "vo_internal.h"
+
+#define DIM 128
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned long long u64;
+
+#define KEY_NONE (~0ull)
+
+__device__ __forceinline__ void top2_insert(u64 key, u64 &b0, u64 &b1)
+{
+    const u64 lo = key < b0 ? key : b0;
+    const u64 hi = key < b0 ? b0 : key;
+    b0 = lo;
+    b1 = hi < b1 ? hi : b1;
+}
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+{
+    const unsigned lo = __shfl_xor((unsigned)v, mask, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// rows [0, n) of src -> bf16 rows of dst (rows [n, n_pad) zero), squared norms, integer flag.
+// 16 lanes per row, 8 entries per lane.
+__global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict__ src, int n, int n_pad,
+                                                        unsigned short *__restrict__ dst, float *__restrict__ norm,
+                                                        unsigned *__restrict__ not_bytes)
+{
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 8;
+    if (row >= n_pad) return;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < n) {
+        const float4 a = *(const float4 *)(src + (int64_t)row * DIM + c);
+        const float4 b = *(const float4 *)(src + (int64_t)row * DIM + c + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    bool bad = false;
+    float s = 0.f;
+    unsigned short h[8];
+    for (int j = 0; j < 8; ++j) {
+        bad |= !(v[j] >= 0.f && v[j] <= 255.f && v[j] == floorf(v[j]));
+        s = fmaf(v[j], v[j], s);
+        h[j] = (unsigned short)(__float_as_uint(v[j]) >> 16);
+    }
+    uint4 o;
+    o.x = h[0] | ((unsigned)h[1] << 16);
+    o.y = h[2] | ((unsigned)h[3] << 16);
+    o.z = h[4] | ((unsigned)h[5] << 16);
+    o.w = h[6] | ((unsigned)h[7] << 16);
+    *(uint4 *)(dst + (int64_t)row * DIM + c) = o;
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 15) == 0) norm[row] = s;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(not_bytes, 1u);
+}
+
+// Matrix-core path.  A wavefront owns 32 queries (operand B, held in registers for the
+// whole launch) and walks its split of the train set in tiles of 32 (operand A, read
+// straight from global memory: 16 contiguous bytes per lane and k-step).  The result
+// tile has the query on the lane and 16 trains in the registers, so each lane keeps the
+// two best keys of its query without cross-lane traffic; the two lane halves are merged
+// once at the end.
+__global__ __launch_bounds__(256) void knn2_mfma_kernel(const unsigned short *__restrict__ Q, const float *__restrict__ nq,
+                                                        const unsigned short *__restrict__ T, const float *__restrict__ nt,
+                                                        int n1, int n2, int tiles_per_split,
+                                                        const unsigned *__restrict__ not_bytes, u64 *__restrict__ part)
+{
+    if (*not_bytes) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q = (blockIdx.x * 4 + wave) * 32 + r;  // < n1 padded to 128
+    bf16x8 b[8];
+    for (int s = 0; s < 8; ++s) b[s] = *(const bf16x8 *)(Q + (int64_t)q * DIM + 16 * s + 8 * h);
+    const float qq = nq[q];
+    const int n_tiles = (n2 + 31) >> 5;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    const int tile1 = min(tile0 + tiles_per_split, n_tiles);
+    u64 b0 = KEY_NONE, b1 = KEY_NONE;
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int t0 = tile * 32;
+        bf16x8 a[8];
+        for (int s = 0; s < 8; ++s) a[s] = *(const bf16x8 *)(T + (int64_t)(t0 + r) * DIM + 16 * s + 8 * h);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+            const int tb = t0 + 8 * g + 4 * h;
+            const float4 tt = *(const float4 *)(nt + tb);
+            const float tn[4] = {tt.x, tt.y, tt.z, tt.w};
+            for (int e = 0; e < 4; ++e) {
+                const float d2 = fmaf(-2.f, acc[4 * g + e], qq + tn[e]);
+                const int t = tb + e;
+                const u64 key = t < n2 ? (((u64)__float_as_uint(d2) << 32) | (unsigned)t) : KEY_NONE;
+                top2_insert(key, b0, b1);
+            }
+        }
+    }
+    const u64 o0 = shfl_xor_u64(b0, 32), o1 = shfl_xor_u64(b1, 32);
+    top2_insert(o0, b0, b1);
+    top2_insert(o1, b0, b1);
+    if (h == 0 && q < n1) {
+        part[((int64_t)blockIdx.y * n1 + q) * 2] = b0;
+        part[((int64_t)blockIdx.y * n1 + q) * 2 + 1] = b1;
+    }
+}
+
+// General float path: 64 queries x 64 trains per workgroup step, both tiles in LDS with a
+// row pitch of 132 floats (16-byte reads of 16 different rows land in different banks);
+// a lane owns a 4x4 block of pairs and adds the 128 terms of each in ascending k.
+#define FP 132
+__global__ __launch_bounds__(256) void knn2_f32_kernel(const float *__restrict__ D1, const float *__restrict__ D2, int n1, int n2,
+                                                       int tiles_per_split, const unsigned *__restrict__ not_bytes,
+                                                       u64 *__restrict__ part)
+{
+    if (!*not_bytes) return;
+    __shared__ float qs[64 * FP];
+    __shared__ float ts[64 * FP];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int q0 = blockIdx.x * 64;
+    for (int e = 0; e < 8; ++e) {
+        const int i = e * 256 + tid, row = i >> 5, c4 = i & 31;
+        const int src = min(q0 + row, n1 - 1);
+        *(float4 *)(qs + row * FP + 4 * c4) = *(const float4 *)(D1 + (int64_t)src * DIM + 4 * c4);
+    }
+    const int n_tiles = (n2 + 63) >> 6;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    const int tile1 = min(tile0 + tiles_per_split, n_tiles);
+    u64 b0[4], b1[4];
+    for (int i = 0; i < 4; ++i) { b0[i] = KEY_NONE; b1[i] = KEY_NONE; }
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int t0 = tile * 64;
+        __syncthreads();  // previous tile fully consumed (and the query tile stored)
+        for (int e = 0; e < 8; ++e) {
+            const int i = e * 256 + tid, row = i >> 5, c4 = i & 31;
+            const int src = min(t0 + row, n2 - 1);
+            *(float4 *)(ts + row * FP + 4 * c4) = *(const float4 *)(D2 + (int64_t)src * DIM + 4 * c4);
+        }
+        __syncthreads();
+        float acc[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int k4 = 0; k4 < 32; ++k4) {
+            float4 qv[4], tv[4];
+            for (int i = 0; i < 4; ++i) qv[i] = *(const float4 *)(qs + (ty * 4 + i) * FP + 4 * k4);
+            for (int j = 0; j < 4; ++j) tv[j] = *(const float4 *)(ts + (tx + 16 * j) * FP + 4 * k4);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    float d;
+                    d = qv[i].x - tv[j].x; acc[i][j] = fmaf(d, d, acc[i][j]);
+                    d = qv[i].y - tv[j].y; acc[i][j] = fmaf(d, d, acc[i][j]);
+                    d = qv[i].z - tv[j].z; acc[i][j] = fmaf(d, d, acc[i][j]);
+                    d = qv[i].w - tv[j].w; acc[i][j] = fmaf(d, d, acc[i][j]);
+                }
+        }
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + tx + 16 * j;
+            for (int i = 0; i < 4; ++i) {
+                const u64 key = t < n2 ? (((u64)__float_as_uint(acc[i][j]) << 32) | (unsigned)t) : KEY_NONE;
+                top2_insert(key, b0[i], b1[i]);
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        for (int m = 1; m < 16; m <<= 1) {
+            const u64 o0 = shfl_xor_u64(b0[i], m), o1 = shfl_xor_u64(b1[i], m);
+            top2_insert(o0, b0[i], b1[i]);
+            top2_insert(o1, b0[i], b1[i]);
+        }
+        const int q = q0 + ty * 4 + i;
+        if (tx == 0 && q < n1) {
+            part[((int64_t)blockIdx.y * n1 + q) * 2] = b0[i];
+            part[((int64_t)blockIdx.y * n1 + q) * 2 + 1] = b1[i];
+        }
+    }
+}
+
+// One lane per query: best two keys over the splits, distances, ratio test.
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const u64 *__restrict__ part, int n1, int splits, double ratio,
+                                                         int32_t *__restrict__ idx, float *__restrict__ dist,
+                                                         uint8_t *__restrict__ keep)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n1) return;
+    u64 b0 = KEY_NONE, b1 = KEY_NONE;
+    for (int s = 0; s < splits; ++s) {
+        top2_insert(part[((int64_t)s * n1 + q) * 2], b0, b1);
+        top2_insert(part[((int64_t)s * n1 + q) * 2 + 1], b0, b1);
+    }
+    const float inf = __uint_as_float(0x7f800000u);
+    const float d0 = b0 == KEY_NONE ? inf : sqrtf(__uint_as_float((unsigned)(b0 >> 32)));
+    const float d1 = b1 == KEY_NONE ? inf : sqrtf(__uint_as_float((unsigned)(b1 >> 32)));
+    idx[2 * (int64_t)q] = b0 == KEY_NONE ? -1 : (int32_t)(unsigned)b0;
+    idx[2 * (int64_t)q + 1] = b1 == KEY_NONE ? -1 : (int32_t)(unsigned)b1;
+    dist[2 * (int64_t)q] = d0;
+    dist[2 * (int64_t)q + 1] = d1;
+    if (keep) keep[q] = (b1 != KEY_NONE && (double)d0 < ratio * (double)d1) ? 1 : 0;
+}
+
+static int div_up(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float *des2, int n2, int dim, double ratio,
+                             int32_t *idx, float *dist, uint8_t *keep, int mem)
+{
+    VO_REQUIRE(ctx != nullptr, "vo_knn_match2: ctx is NULL");
+    VO_REQUIRE(dim == DIM, "vo_knn_match2: descriptors of %d entries (this library matches 128-entry descriptors)", dim);
+    VO_REQUIRE(n1 >= 0 && n2 >= 0, "vo_knn_match2: n1=%d n2=%d", n1, n2);
+    VO_REQUIRE(n1 <= (1 << 22) && n2 <= (1 << 22), "vo_knn_match2: at most %d descriptors per set", 1 << 22);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_knn_match2: bad mem flag %d", mem);
+    if (n1 == 0) return VO_OK;
+    VO_REQUIRE(des1 && idx && dist && (des2 || n2 == 0), "vo_knn_match2: NULL buffer");
+    VO_REQUIRE(mem == VO_MEM_HOST || (((uintptr_t)des1 & 15) == 0 && ((uintptr_t)des2 & 15) == 0),
+               "vo_knn_match2: device descriptors must be 16-byte aligned");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    void *p;
+    const float *d1 = des1, *d2 = des2;
+    int32_t *d_idx = idx;
+    float *d_dist = dist;
+    uint8_t *d_keep = keep;
+    if (mem == VO_MEM_HOST) {
+        const size_t b1 = (size_t)n1 * DIM * 4, b2 = (size_t)n2 * DIM * 4;
+        if ((rc = vo_stage_reserve(ctx, 0, b1, &p))) return rc; d1 = (const float *)p;
+        if ((rc = vo_stage_reserve(ctx, 1, b2, &p))) return rc; d2 = (const float *)p;
+        // idx (n1,2) int32 | dist (n1,2) float | keep (n1)
+        if ((rc = vo_stage_reserve(ctx, 2, (size_t)n1 * 17, &p))) return rc;
+        d_idx = (int32_t *)p;
+        d_dist = (float *)((char *)p + (size_t)n1 * 8);
+        d_keep = keep ? (uint8_t *)p + (size_t)n1 * 16 : nullptr;
+        VO_HIP_CHECK(hipMemcpyAsync((void *)d1, des1, b1, hipMemcpyHostToDevice, st));
+        if (n2) VO_HIP_CHECK(hipMemcpyAsync((void *)d2, des2, b2, hipMemcpyHostToDevice, st));
+    }
+    const int n1p = div_up(n1, 128) * 128, n2p = div_up(n2 > 0 ? n2 : 1, 64) * 64;
+    // split the train set so that the launch has a few hundred workgroups
+    const int tiles64 = n2p / 64;
+    int splits = div_up(1024, div_up(n1, 64));
+    if (splits > tiles64) splits = tiles64;
+    if (splits < 1) splits = 1;
+    const int tiles64_per_split = div_up(tiles64, splits);
+    splits = div_up(tiles64, tiles64_per_split);
+    // bf16 copies | norms | flag | per-split candidate keys
+    const size_t off_t = (size_t)n1p * DIM * 2, off_nq = off_t + (size_t)n2p * DIM * 2, off_nt = off_nq + (size_t)n1p * 4,
+                 off_flag = off_nt + (size_t)n2p * 4, off_part = (off_flag + 4 + 15) / 16 * 16,
+                 total = off_part + (size_t)splits * n1 * 16;
+    if ((rc = vo_stage_reserve(ctx, 3, total, &p))) return rc;
+    char *w = (char *)p;
+    unsigned short *Qh = (unsigned short *)w, *Th = (unsigned short *)(w + off_t);
+    float *nq = (float *)(w + off_nq), *nt = (float *)(w + off_nt);
+    unsigned *flag = (unsigned *)(w + off_flag);
+    u64 *part = (u64 *)(w + off_part);
+    VO_HIP_CHECK(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(desc_pack_kernel, dim3(n1p / 16), dim3(256), 0, st, d1, n1, n1p, Qh, nq, flag);
+    hipLaunchKernelGGL(desc_pack_kernel, dim3(n2p / 16), dim3(256), 0, st, d2, n2, n2p, Th, nt, flag);
+    if (n2 > 0) {
+        hipLaunchKernelGGL(knn2_mfma_kernel, dim3(n1p / 128, splits), dim3(256), 0, st, Qh, nq, Th, nt, n1, n2,
+                           2 * tiles64_per_split, flag, part);
+        hipLaunchKernelGGL(knn2_f32_kernel, dim3(div_up(n1, 64), splits), dim3(256), 0, st, d1, d2, n1, n2, tiles64_per_split,
+                           flag, part);
+    }
+    hipLaunchKernelGGL(knn2_merge_kernel, dim3(div_up(n1, 256)), dim3(256), 0, st, part, n1, n2 > 0 ? splits : 0, ratio, d_idx,
+                       d_dist, d_keep);
+    VO_HIP_CHECK(hipGetLastError());
+    if (mem == VO_MEM_HOST) {
+        VO_HIP_CHECK(hipMemcpyAsync(idx, d_idx, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+        VO_HIP_CHECK(hipMemcpyAsync(dist, d_dist, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+        if (keep) VO_HIP_CHECK(hipMemcpyAsync(keep, d_keep, (size_t)n1, hipMemcpyDeviceToHost, st));
+        VO_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return VO_OK;
+}

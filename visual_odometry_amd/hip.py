@@ -464,6 +464,36 @@ def triangulate(ctx: Context, pts1, pts2, M1, M2):
     return out
 
 
+def knn_match2(ctx: Context, des1, des2, ratio: float = 0.8):
+    """Two nearest rows of des2 (n2,128) for every row of des1 (n1,128), exhaustive float32 L2 search.
+    Returns (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8); keep = dist[:,0] < ratio * dist[:,1].
+    A missing neighbour is index -1 at distance inf."""
+    if _is_torch(des1):
+        import torch
+        if not _is_torch(des2) or des1.dtype != torch.float32 or des2.dtype != torch.float32:
+            raise ValueError("knn_match2: device descriptors must both be float32 tensors")
+        des1, des2 = des1.contiguous(), des2.contiguous()
+        mem = VO_MEM_DEVICE
+    else:
+        des1 = np.ascontiguousarray(des1, np.float32)
+        des2 = np.ascontiguousarray(des2, np.float32)
+        mem = VO_MEM_HOST
+    if des1.ndim != 2 or des2.ndim != 2 or des1.shape[1] != des2.shape[1]:
+        raise ValueError("knn_match2: descriptors must be (n1,d) and (n2,d), got %s and %s" % (tuple(des1.shape), tuple(des2.shape)))
+    n1, n2, dim = int(des1.shape[0]), int(des2.shape[0]), int(des1.shape[1])
+    if mem == VO_MEM_DEVICE:
+        idx = torch.empty((n1, 2), dtype=torch.int32, device=des1.device)
+        dist = torch.empty((n1, 2), dtype=torch.float32, device=des1.device)
+        keep = torch.empty((n1,), dtype=torch.uint8, device=des1.device)
+    else:
+        idx = np.empty((n1, 2), np.int32)
+        dist = np.empty((n1, 2), np.float32)
+        keep = np.empty((n1,), np.uint8)
+    check(ctx.lib.vo_knn_match2(ctx.handle, _ptr(des1), n1, _ptr(des2), n2, dim, float(ratio), _ptr(idx), _ptr(dist),
+                                _ptr(keep), mem), "vo_knn_match2")
+    return idx, dist, keep
+
+
 class BaSolver:
     """Device-resident Levenberg-Marquardt state of one bundle-adjustment window (vo_ba_*).
     ci, pi, obs may be numpy arrays or torch tensors on the context's device; K is host."""

@@ -148,6 +148,33 @@ def ba_problem(F=10, P=5000, K=K_KITTI, visibility=1.0, seed=0, obs_noise=0.5):
                 F=F, P=P)
 
 
+def sift_like_descriptors(n1=3000, n2=3000, shared=0.6, jitter=6.0, seed=5):
+    """Two sets of 128-entry descriptors shaped like SIFT's: non-negative, normalised to length 512,
+    entries clipped and rounded to bytes, stored as float32.  The first `shared * min(n1, n2)` rows of
+    the first set reappear (perturbed, at shuffled rows) in the second; the rest are unrelated.
+    Returns (des1, des2, truth) with truth[q] = row of des2 that des1[q] was copied to, or -1."""
+    rng = np.random.default_rng(seed)
+
+    def finish(x):
+        x = np.maximum(x, 0)
+        x *= 512.0 / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+        return np.minimum(np.rint(x), 255).astype(np.float32)
+
+    base1 = rng.gamma(0.6, 1.0, (n1, 128))
+    des1 = finish(base1.copy())
+    m = int(shared * min(n1, n2))
+    base2 = rng.gamma(0.6, 1.0, (n2, 128))
+    perm = rng.permutation(n2)
+    truth = np.full(n1, -1, np.int64)
+    if m:
+        base2[perm[:m]] = des1[:m] / 512.0 * np.linalg.norm(base1[:m], axis=1, keepdims=True)
+        truth[:m] = perm[:m]
+    des2 = finish(base2)
+    if m:
+        des2[perm[:m]] = np.clip(np.rint(des1[:m] + rng.normal(0, jitter, (m, 128))), 0, 255).astype(np.float32)
+    return des1, des2, truth
+
+
 class BoxScene:
     """Seeded piecewise-planar 3-D scene (back wall, ground, fronto-parallel box faces) seen by a
     camera that mostly translates sideways, in the manner of the 640x480 parking sequence.
