@@ -150,6 +150,32 @@ def main():
                 "ms": ms_f, "frames_per_s": B / (ms_f * 1e-3), "algorithmic_bytes_per_frame": nbytes,
                 "roofline": {"bound": "hbm", "achieved": nbytes * B / (ms_f * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
                              "frac": nbytes * B / (ms_f * 1e-3) / 1e9 / HBM}})
+    # ---- descriptor matching: two nearest neighbours + ratio test ------------------
+    MFMA_BF16 = 2500.0          # dense bf16 peak, TFLOP/s
+    for n1, n2, kind in [(3000, 3000, "bytes"), (3000, 3000, "float"), (16384, 16384, "bytes"), (16384, 16384, "float")]:
+        d1, d2, _ = synth.sift_like_descriptors(n1, n2, seed=5)
+        if kind == "float":
+            d1, d2 = d1 * np.float32(1.0 / 512), d2 * np.float32(1.0 / 512)
+        a, b = torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev)
+        ms = timed(ctx, lambda: hip.knn_match2(ctx, a, b, 0.8))
+        flop = 2.0 * n1 * n2 * 128
+        rec = {"op": "knn_match2", "workload": f"{n1} x {n2} descriptors of 128 entries, {kind} "
+               f"({'bf16 matrix-core kernel' if kind == 'bytes' else 'float32 kernel'}), 2-NN + ratio test, device-resident",
+               "ms": ms, "pairs_per_s": n1 * n2 / (ms * 1e-3), "algorithmic_flop": flop,
+               "algorithmic_bytes": (n1 + n2) * 512 + n1 * 17}
+        if kind == "bytes":
+            rec["roofline"] = {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_BF16, "unit": "TFLOP/s",
+                               "frac": flop / (ms * 1e-3) / 1e12 / MFMA_BF16}
+        if n1 == 3000:
+            rec["cpu_oracle_ms"] = cpu_time(lambda: oracle.knn_match2(d1, d2, 0.8))
+            rec["cpu_cores"] = 1
+            t0 = time.perf_counter()
+            for _ in range(20):
+                hip.knn_match2(ctx, d1, d2, 0.8)
+            rec["ms_host_arrays_sync"] = (time.perf_counter() - t0) / 20 * 1e3
+        out.append(rec)
+        del a, b
+
     for o in out:
         print(json.dumps(o), flush=True)
 

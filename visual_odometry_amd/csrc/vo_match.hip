@@ -41,15 +41,23 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
     return ((u64)hi << 32) | lo;
 }
 
-// rows [0, n) of src -> bf16 rows of dst (rows [n, n_pad) zero), squared norms, integer flag.
+// rows [0, n) of a set -> bf16 rows (padding rows zero), squared norms, integer flag.
 // 16 lanes per row, 8 entries per lane.
-__global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict__ src, int n, int n_pad,
-                                                        unsigned short *__restrict__ dst, float *__restrict__ norm,
+// One launch packs both sets: workgroups [0, blocks1) take the query set, the rest the train set.
+__global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict__ src1, int n1, int blocks1,
+                                                        unsigned short *__restrict__ dst1, float *__restrict__ norm1,
+                                                        const float *__restrict__ src2, int n2,
+                                                        unsigned short *__restrict__ dst2, float *__restrict__ norm2,
                                                         unsigned *__restrict__ not_bytes)
 {
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool second = (int)blockIdx.x >= blocks1;
+    const float *__restrict__ src = second ? src2 : src1;
+    unsigned short *__restrict__ dst = second ? dst2 : dst1;
+    float *__restrict__ norm = second ? norm2 : norm1;
+    const int n = second ? n2 : n1;
+    const float pad_norm = second ? __uint_as_float(0x7f800000u) : 0.f;   // padding trains are infinitely far
+    const int row = ((int)blockIdx.x - (second ? blocks1 : 0)) * 16 + (threadIdx.x >> 4);
     const int c = (threadIdx.x & 15) * 8;
-    if (row >= n_pad) return;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < n) {
         const float4 a = *(const float4 *)(src + (int64_t)row * DIM + c);
@@ -70,58 +78,98 @@ __global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict_
     o.y = h[2] | ((unsigned)h[3] << 16);
     o.z = h[4] | ((unsigned)h[5] << 16);
     o.w = h[6] | ((unsigned)h[7] << 16);
-    *(uint4 *)(dst + (int64_t)row * DIM + c) = o;
+    // fragment order of the 32x32x16 matrix-core product: [tile of 32 rows][k-step s][k-half h][row in tile][8 entries],
+    // so that the 64 lanes of a wavefront read one contiguous KB per k-step
+    const int chunk = threadIdx.x & 15;
+    *(uint4 *)(dst + ((((int64_t)(row >> 5) * 8 + (chunk >> 1)) * 2 + (chunk & 1)) * 32 + (row & 31)) * 8) = o;
     for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-    if ((threadIdx.x & 15) == 0) norm[row] = s;
+    if ((threadIdx.x & 15) == 0) norm[row] = row < n ? s : pad_norm;
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(not_bytes, 1u);
 }
 
-// Matrix-core path.  A wavefront owns 32 queries (operand B, held in registers for the
+// Matrix-core path.  A wavefront owns 64 queries (two operands B, held in registers for the
 // whole launch) and walks its split of the train set in tiles of 32 (operand A, read
-// straight from global memory: 16 contiguous bytes per lane and k-step).  The result
-// tile has the query on the lane and 16 trains in the registers, so each lane keeps the
-// two best keys of its query without cross-lane traffic; the two lane halves are merged
-// once at the end.
+// straight from global memory, 16 contiguous bytes per lane and k-step; the reads of the
+// next tile are issued before the products of the current one).  The result tile has the
+// query on the lane and 16 trains in the registers, so each lane keeps the two best keys
+// of its query without cross-lane traffic; the two lane halves are merged once at the end.
+// A lane visits its trains in ascending order, so a candidate can only enter the pair when
+// its squared distance is below the second best: the wavefront tests the minimum of the
+// 16 new values first and touches the keys only for elements some lane accepts.  Padding
+// trains carry an infinite norm and never pass that test.
 __global__ __launch_bounds__(256) void knn2_mfma_kernel(const unsigned short *__restrict__ Q, const float *__restrict__ nq,
                                                         const unsigned short *__restrict__ T, const float *__restrict__ nt,
                                                         int n1, int n2, int tiles_per_split,
                                                         const unsigned *__restrict__ not_bytes, u64 *__restrict__ part)
 {
-    if (*not_bytes) return;
+    const unsigned other_path = __builtin_nontemporal_load(not_bytes);   // tested after the operand reads are issued
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int q = (blockIdx.x * 4 + wave) * 32 + r;  // < n1 padded to 128
-    bf16x8 b[8];
-    for (int s = 0; s < 8; ++s) b[s] = *(const bf16x8 *)(Q + (int64_t)q * DIM + 16 * s + 8 * h);
-    const float qq = nq[q];
+    const int qt = (blockIdx.x * 4 + wave) * 2;      // first of the wavefront's two query tiles; n1 is padded to 256
+    bf16x8 b[2][8];
+    float qq[2];
+    for (int u = 0; u < 2; ++u) {
+        for (int s = 0; s < 8; ++s) b[u][s] = *(const bf16x8 *)(Q + (((int64_t)(qt + u) * 8 + s) * 64 + lane) * 8);
+        qq[u] = nq[(qt + u) * 32 + r];
+    }
     const int n_tiles = (n2 + 31) >> 5;
     const int tile0 = blockIdx.y * tiles_per_split;
     const int tile1 = min(tile0 + tiles_per_split, n_tiles);
-    u64 b0 = KEY_NONE, b1 = KEY_NONE;
+    u64 b0[2] = {KEY_NONE, KEY_NONE}, b1[2] = {KEY_NONE, KEY_NONE};
+    float thr[2] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
+    bf16x8 a[8];
+    float4 tn[4];
+    if (tile0 < tile1) {
+        for (int s = 0; s < 8; ++s) a[s] = *(const bf16x8 *)(T + (((int64_t)tile0 * 8 + s) * 64 + lane) * 8);
+        for (int g = 0; g < 4; ++g) tn[g] = *(const float4 *)(nt + tile0 * 32 + 8 * g + 4 * h);
+    }
+    if (other_path) return;
     for (int tile = tile0; tile < tile1; ++tile) {
         const int t0 = tile * 32;
-        bf16x8 a[8];
-        for (int s = 0; s < 8; ++s) a[s] = *(const bf16x8 *)(T + (int64_t)(t0 + r) * DIM + 16 * s + 8 * h);
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
-        for (int g = 0; g < 4; ++g) {
-            const int tb = t0 + 8 * g + 4 * h;
-            const float4 tt = *(const float4 *)(nt + tb);
-            const float tn[4] = {tt.x, tt.y, tt.z, tt.w};
-            for (int e = 0; e < 4; ++e) {
-                const float d2 = fmaf(-2.f, acc[4 * g + e], qq + tn[e]);
-                const int t = tb + e;
-                const u64 key = t < n2 ? (((u64)__float_as_uint(d2) << 32) | (unsigned)t) : KEY_NONE;
-                top2_insert(key, b0, b1);
+        const int tp = min(tile + 1, tile1 - 1);          // the last step reads its own tile again
+        bf16x8 an[8];
+        float4 tnn[4];
+        for (int s = 0; s < 8; ++s) an[s] = *(const bf16x8 *)(T + (((int64_t)tp * 8 + s) * 64 + lane) * 8);
+        for (int g = 0; g < 4; ++g) tnn[g] = *(const float4 *)(nt + tp * 32 + 8 * g + 4 * h);
+        f32x16 acc[2];
+        for (int u = 0; u < 2; ++u)
+            for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+        for (int s = 0; s < 8; ++s)
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[u][s], acc[u], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+            float d2[16];
+            for (int g = 0; g < 4; ++g) {
+                d2[4 * g] = fmaf(-2.f, acc[u][4 * g], qq[u] + tn[g].x);
+                d2[4 * g + 1] = fmaf(-2.f, acc[u][4 * g + 1], qq[u] + tn[g].y);
+                d2[4 * g + 2] = fmaf(-2.f, acc[u][4 * g + 2], qq[u] + tn[g].z);
+                d2[4 * g + 3] = fmaf(-2.f, acc[u][4 * g + 3], qq[u] + tn[g].w);
+            }
+            float m = fminf(d2[0], d2[1]);
+            for (int e = 2; e < 16; e += 2) m = fminf(m, fminf(d2[e], d2[e + 1]));
+            if (__any(m < thr[u])) {
+                for (int e = 0; e < 16; ++e) {
+                    const bool take = d2[e] < thr[u];
+                    if (__any(take)) {
+                        const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const u64 key = take ? (((u64)__float_as_uint(d2[e]) << 32) | (unsigned)t) : KEY_NONE;
+                        top2_insert(key, b0[u], b1[u]);
+                        thr[u] = __uint_as_float(min((unsigned)(b1[u] >> 32), 0x7f800000u));
+                    }
+                }
             }
         }
+        for (int s = 0; s < 8; ++s) a[s] = an[s];
+        for (int g = 0; g < 4; ++g) tn[g] = tnn[g];
     }
-    const u64 o0 = shfl_xor_u64(b0, 32), o1 = shfl_xor_u64(b1, 32);
-    top2_insert(o0, b0, b1);
-    top2_insert(o1, b0, b1);
-    if (h == 0 && q < n1) {
-        part[((int64_t)blockIdx.y * n1 + q) * 2] = b0;
-        part[((int64_t)blockIdx.y * n1 + q) * 2 + 1] = b1;
+    for (int u = 0; u < 2; ++u) {
+        const u64 o0 = shfl_xor_u64(b0[u], 32), o1 = shfl_xor_u64(b1[u], 32);
+        top2_insert(o0, b0[u], b1[u]);
+        top2_insert(o1, b0[u], b1[u]);
+        const int q = (qt + u) * 32 + r;
+        if (h == 0 && q < n1) {
+            part[((int64_t)blockIdx.y * n1 + q) * 2] = b0[u];
+            part[((int64_t)blockIdx.y * n1 + q) * 2 + 1] = b1[u];
+        }
     }
 }
 
@@ -195,18 +243,27 @@ __global__ __launch_bounds__(256) void knn2_f32_kernel(const float *__restrict__
     }
 }
 
-// One lane per query: best two keys over the splits, distances, ratio test.
-__global__ __launch_bounds__(256) void knn2_merge_kernel(const u64 *__restrict__ part, int n1, int splits, double ratio,
+// Sixteen lanes per query share the splits; best two keys, distances, ratio test.
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const u64 *__restrict__ part, int n1, int splits_bytes,
+                                                         int splits_float, const unsigned *__restrict__ not_bytes, double ratio,
                                                          int32_t *__restrict__ idx, float *__restrict__ dist,
                                                          uint8_t *__restrict__ keep)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= n1) return;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int splits = *not_bytes ? splits_float : splits_bytes;
     u64 b0 = KEY_NONE, b1 = KEY_NONE;
-    for (int s = 0; s < splits; ++s) {
-        top2_insert(part[((int64_t)s * n1 + q) * 2], b0, b1);
-        top2_insert(part[((int64_t)s * n1 + q) * 2 + 1], b0, b1);
+    if (q < n1)
+        for (int s = sub; s < splits; s += 16) {
+            const ulonglong2 k = *(const ulonglong2 *)(part + ((int64_t)s * n1 + q) * 2);
+            top2_insert(k.x, b0, b1);
+            top2_insert(k.y, b0, b1);
+        }
+    for (int m = 1; m < 16; m <<= 1) {
+        const u64 o0 = shfl_xor_u64(b0, m), o1 = shfl_xor_u64(b1, m);
+        top2_insert(o0, b0, b1);
+        top2_insert(o1, b0, b1);
     }
+    if (q >= n1 || sub != 0) return;
     const float inf = __uint_as_float(0x7f800000u);
     const float d0 = b0 == KEY_NONE ? inf : sqrtf(__uint_as_float((unsigned)(b0 >> 32)));
     const float d1 = b1 == KEY_NONE ? inf : sqrtf(__uint_as_float((unsigned)(b1 >> 32)));
@@ -251,18 +308,22 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
         VO_HIP_CHECK(hipMemcpyAsync((void *)d1, des1, b1, hipMemcpyHostToDevice, st));
         if (n2) VO_HIP_CHECK(hipMemcpyAsync((void *)d2, des2, b2, hipMemcpyHostToDevice, st));
     }
-    const int n1p = div_up(n1, 128) * 128, n2p = div_up(n2 > 0 ? n2 : 1, 64) * 64;
-    // split the train set so that the launch has a few hundred workgroups
-    const int tiles64 = n2p / 64;
+    const int n1p = div_up(n1, 256) * 256, n2p = div_up(n2 > 0 ? n2 : 1, 64) * 64;
+    // split the train set so that each launch has about a thousand workgroups
+    const int tiles64 = n2p / 64, tiles32 = n2p / 32;
     int splits = div_up(1024, div_up(n1, 64));
     if (splits > tiles64) splits = tiles64;
-    if (splits < 1) splits = 1;
     const int tiles64_per_split = div_up(tiles64, splits);
     splits = div_up(tiles64, tiles64_per_split);
+    int splits_m = div_up(1024, n1p / 256);
+    if (splits_m > tiles32) splits_m = tiles32;
+    const int tiles32_per_split = div_up(tiles32, splits_m);
+    splits_m = div_up(tiles32, tiles32_per_split);
+    const int max_splits = splits > splits_m ? splits : splits_m;
     // bf16 copies | norms | flag | per-split candidate keys
     const size_t off_t = (size_t)n1p * DIM * 2, off_nq = off_t + (size_t)n2p * DIM * 2, off_nt = off_nq + (size_t)n1p * 4,
                  off_flag = off_nt + (size_t)n2p * 4, off_part = (off_flag + 4 + 15) / 16 * 16,
-                 total = off_part + (size_t)splits * n1 * 16;
+                 total = off_part + (size_t)max_splits * n1 * 16;
     if ((rc = vo_stage_reserve(ctx, 3, total, &p))) return rc;
     char *w = (char *)p;
     unsigned short *Qh = (unsigned short *)w, *Th = (unsigned short *)(w + off_t);
@@ -270,15 +331,16 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
     unsigned *flag = (unsigned *)(w + off_flag);
     u64 *part = (u64 *)(w + off_part);
     VO_HIP_CHECK(hipMemsetAsync(flag, 0, 4, st));
-    hipLaunchKernelGGL(desc_pack_kernel, dim3(n1p / 16), dim3(256), 0, st, d1, n1, n1p, Qh, nq, flag);
-    hipLaunchKernelGGL(desc_pack_kernel, dim3(n2p / 16), dim3(256), 0, st, d2, n2, n2p, Th, nt, flag);
+    hipLaunchKernelGGL(desc_pack_kernel, dim3(n1p / 16 + n2p / 16), dim3(256), 0, st, d1, n1, n1p / 16, Qh, nq, d2, n2, Th, nt,
+                       flag);
     if (n2 > 0) {
-        hipLaunchKernelGGL(knn2_mfma_kernel, dim3(n1p / 128, splits), dim3(256), 0, st, Qh, nq, Th, nt, n1, n2,
-                           2 * tiles64_per_split, flag, part);
+        hipLaunchKernelGGL(knn2_mfma_kernel, dim3(n1p / 256, splits_m), dim3(256), 0, st, Qh, nq, Th, nt, n1, n2,
+                           tiles32_per_split, flag, part);
         hipLaunchKernelGGL(knn2_f32_kernel, dim3(div_up(n1, 64), splits), dim3(256), 0, st, d1, d2, n1, n2, tiles64_per_split,
                            flag, part);
     }
-    hipLaunchKernelGGL(knn2_merge_kernel, dim3(div_up(n1, 256)), dim3(256), 0, st, part, n1, n2 > 0 ? splits : 0, ratio, d_idx,
+    hipLaunchKernelGGL(knn2_merge_kernel, dim3(div_up(n1, 16)), dim3(256), 0, st, part, n1, n2 > 0 ? splits_m : 0,
+                       n2 > 0 ? splits : 0, flag, ratio, d_idx,
                        d_dist, d_keep);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
