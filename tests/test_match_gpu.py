@@ -102,3 +102,29 @@ def test_feature_matcher_mirror(ctx, oracle):
     # the reference's own filter generator works on pairs of these objects
     pairs = [(g, g) for g in every[:3]]
     assert list(m.match_filter(pairs)) == []
+
+
+def test_bootstrap_from_descriptors(ctx):
+    """BootstrapInitializer(features=...) takes the reference's descriptor route (bootstrap.py:188-211):
+    keypoints of the second image shuffled, found again through their descriptors, planted motion recovered."""
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    sc = synth.two_view_scene(n=800, inlier_frac=1.0, noise=0.02, seed=21)
+    des0, des1, truth = synth.sift_like_descriptors(800, 900, shared=1.0, seed=8)
+    kp1 = np.zeros((900, 2), np.float32)
+    kp1[:] = 5.0
+    kp1[truth] = sc["m2"]
+
+    class Kp:
+        def __init__(self, xy):
+            self.pt = (float(xy[0]), float(xy[1]))
+
+    for kp0_in, kp1_in in ((sc["m1"], kp1), ([Kp(p) for p in sc["m1"]], [Kp(p) for p in kp1])):
+        b = BootstrapInitializer(None, None, sc["K"].astype(np.float32), features=(kp0_in, des0, kp1_in, des1))
+        n = b.pts1.shape[0]
+        assert n > 600 and b.pts2.shape == (n, 3) and b.pts_des1.shape == (n, 128) and b.point_cloud.shape == (n, 4)
+        assert b.kps.shape == (900, 2)
+        np.testing.assert_allclose(b.T[:3, :3], sc["R"], atol=5e-3)
+        assert b.T[:3, 3] @ (sc["t"] / np.linalg.norm(sc["t"])) > 0.999
+        # descriptors travel with their points
+        row = np.nonzero((sc["m1"] == b.pts1[0, :2]).all(1))[0][0]
+        assert (b.pts_des1[0] == des0[row]).all() and (b.pts_des2[0] == des1[truth[row]]).all()

@@ -1,11 +1,13 @@
 """BootstrapInitializer -- two-view initialisation with the reference's API and
 attributes (vo_pipeline/bootstrap.py:13-261).
 
-Differences that follow from the scope of this build: correspondences come from
-Shi-Tomasi corners tracked with the pyramidal LK kernel instead of SIFT + FLANN
-(descriptors pts_des1/pts_des2 are therefore zero-filled (n,128) arrays), and the
-fundamental matrix comes from ransac.find_fundamental_mat (GPU-scored RANSAC)
-instead of cv2.findFundamentalMat.  The two-view geometry after F follows the
+Differences that follow from the scope of this build: SIFT is not computed here.  By
+default correspondences come from Shi-Tomasi corners tracked with the pyramidal LK
+kernel (descriptors pts_des1/pts_des2 are then zero-filled (n,128) arrays); a caller
+that has keypoints and descriptors of both images passes them as `features` and gets
+the reference's route, two-nearest-neighbour matching with the ratio test
+(bootstrap.py:188-211), on the GPU.  The fundamental matrix comes from
+ransac.find_fundamental_mat (GPU-scored RANSAC) instead of cv2.findFundamentalMat.  The two-view geometry after F follows the
 reference step by step (pinned by tests/golden/two_view.npz).
 """
 import logging
@@ -16,11 +18,15 @@ import numpy as np
 from .. import hip, params
 from . import _runtime, ransac
 from .featureExtraction import FeatureExtractor
+from .featureMatching import FeatureMatcher, MatcherType
 from .poseEstimation import PoseEstimation
 
 
 class BootstrapInitializer:
-    def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100):
+    def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100, features=None):
+        """features: optional (kp0, des0, kp1, des1) -- keypoints of the two images as (n,2) arrays of (x, y) or
+        sequences of objects with a `.pt`, and their (n,128) descriptors."""
+        self.features = features
         self.img1 = img1
         self.img2 = img2
         self.K = K
@@ -45,19 +51,43 @@ class BootstrapInitializer:
         """(F (3,3) float64 or None, mask (n,1) uint8) -- the hook the reference fills with cv2.findFundamentalMat."""
         return ransac.find_fundamental_mat(pts0, pts1, ransacReprojThreshold, confidence, maxIters)
 
+    @staticmethod
+    def _keypoint_array(kp) -> np.ndarray:
+        if isinstance(kp, np.ndarray):
+            return np.asarray(kp, np.float32).reshape(-1, 2)
+        return np.array([k.pt for k in kp], np.float32).reshape(-1, 2)
+
+    def _matched_features(self):
+        """Correspondences from descriptors as the reference forms them (bootstrap.py:188-211): best match of
+        every descriptor of image 1 among those of image 2 that passes the ratio test."""
+        kp0, des0, kp1, des1 = self.features
+        kp0, kp1 = self._keypoint_array(kp0), self._keypoint_array(kp1)
+        self.kps = kp1
+        matcher = FeatureMatcher(MatcherType.FLANN, k=2, matching_threshold=params.MATCHING_THRESHOLD)
+        idx, _, keep = matcher.match_arrays(des0, des1)
+        q = np.nonzero(keep)[0]
+        t = idx[q, 0]
+        logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
+        return kp0[q], kp1[t], np.asarray(des0, np.float32)[q], np.asarray(des1, np.float32)[t]
+
     def _estimate_fundamental(self, normalize=False):
+        if self.features is not None:
+            kp0, kp1, des0, des1 = self._matched_features()
+            return self._fundamental_from(kp0, kp1, des0, des1)
         kp0 = FeatureExtractor.corners(self.img1, max_corners=3000, quality=0.01, radius=5)
         kp1, st = PoseEstimation.KLT(self.img1, self.img2, kp0)
         ok = st.ravel() == 1
         kp0, kp1 = kp0[ok], kp1[ok]
         self.kps = kp1
         n = kp0.shape[0]
+        return self._fundamental_from(kp0, kp1, np.zeros((n, 128), dtype=np.float32), np.zeros((n, 128), dtype=np.float32))
+
+    def _fundamental_from(self, kp0, kp1, des0, des1):
+        n = kp0.shape[0]
         pts0 = np.ones((n, 3), dtype=np.float32)
         pts1 = np.ones((n, 3), dtype=np.float32)
         pts0[:, 0:2] = kp0
         pts1[:, 0:2] = kp1
-        des0 = np.zeros((n, 128), dtype=np.float32)
-        des1 = np.zeros((n, 128), dtype=np.float32)
         F, mask = self.findFundamentalMat(pts0[:, 0:2], pts1[:, 0:2], params.RANSAC_REPROJ_THRESHOLD,
                                           params.RANSAC_CONFIDENCE, params.RANSAC_MAX_ITERS)
         if F is None:
