@@ -7,6 +7,8 @@ import numpy as np
 
 from .. import hip, params
 from . import _runtime, ransac
+from .featureExtraction import ExtractorType, FeatureExtractor
+from .featureMatching import FeatureMatcher, MatcherType
 from .trackPoints import TrackPoints
 
 
@@ -28,6 +30,7 @@ class PoseEstimation:
         self.algo_method = None
         self.get_method()
         self.use_KLT = use_KLT
+        self.matcher = FeatureMatcher(MatcherType.FLANN, k=2)
         self.KLT_tracker = TrackPoints(params.KLT_RADIUS, params.KLT_N_ITERS, params.KLT_LAMBDA)
 
     def get_method(self):
@@ -57,14 +60,24 @@ class PoseEstimation:
         return M, inliers
 
     def match_key_points(self, pointcloud: np.ndarray, img0: np.ndarray, img1: np.ndarray) -> np.ndarray:
-        """Track self.prev_kpts from img0 to img1 and keep the found ones (the descriptor
-        branch of the reference, use_KLT=False, needs SIFT and is not part of this build)."""
-        if not self.use_KLT:
-            raise NotImplementedError("descriptor matching is outside the GPU front end; construct with use_KLT=True")
-        pts1, st = self.KLT(img0, img1, self.prev_kpts)
-        found = st == 1
-        pts1 = pts1[found[:, 0]]
-        self.update_prev_kpts(pts1)
+        """use_KLT: track self.prev_kpts from img0 to img1 and keep the found ones.  Otherwise the
+        reference's descriptor branch (poseEstimation.py:96-112): descriptors of both images are matched
+        on the GPU; they come from FeatureExtractor.get_kp, which this build leaves to the caller
+        (it raises NotImplementedError unless overridden with a SIFT implementation)."""
+        if self.use_KLT:
+            pts1, st = self.KLT(img0, img1, self.prev_kpts)
+            found = st == 1
+            pts1 = pts1[found[:, 0]]
+            self.update_prev_kpts(pts1)
+        else:
+            descriptor = FeatureExtractor(ExtractorType.SIFT)
+            kp0, des0 = descriptor.get_kp(img0)
+            kp1, des1 = descriptor.get_kp(img1)
+            matches = self.matcher.match_descriptors(des0, des1)
+            pts1 = np.zeros((len(matches), 2))
+            for i, match in enumerate(matches):
+                pts1[i, :] = kp1[match.trainIdx].pt
+            self.update_prev_kpts(pts1)
         return pts1
 
     @staticmethod
