@@ -97,6 +97,54 @@ __global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict_
 // its squared distance is below the second best: the wavefront tests the minimum of the
 // 16 new values first and touches the keys only for elements some lane accepts.  Padding
 // trains carry an infinite norm and never pass that test.
+struct TrainTile {
+    bf16x8 a[8];
+    float4 tn[4];
+};
+
+__device__ __forceinline__ void load_train_tile(TrainTile &t, const unsigned short *__restrict__ T, const float *__restrict__ nt,
+                                                int tile, int lane, int h)
+{
+    for (int s = 0; s < 8; ++s) t.a[s] = *(const bf16x8 *)(T + (((int64_t)tile * 8 + s) * 64 + lane) * 8);
+    for (int g = 0; g < 4; ++g) t.tn[g] = *(const float4 *)(nt + tile * 32 + 8 * g + 4 * h);
+}
+
+// 32 trains against the wavefront's 64 queries: 16 products, then the two-best update of each lane's two queries.
+__device__ __forceinline__ void match_tile(const TrainTile &t, const bf16x8 (&b)[2][8], const float (&qq)[2], int t0, int h,
+                                           u64 (&b0)[2], u64 (&b1)[2], float (&thr)[2])
+{
+    f32x16 acc[2];
+    for (int u = 0; u < 2; ++u)
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+    for (int s = 0; s < 8; ++s)
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.a[s], b[u][s], acc[u], 0, 0, 0);
+    for (int u = 0; u < 2; ++u) {
+        float d2[16];
+        for (int g = 0; g < 4; ++g) {
+            d2[4 * g] = fmaf(-2.f, acc[u][4 * g], qq[u] + t.tn[g].x);
+            d2[4 * g + 1] = fmaf(-2.f, acc[u][4 * g + 1], qq[u] + t.tn[g].y);
+            d2[4 * g + 2] = fmaf(-2.f, acc[u][4 * g + 2], qq[u] + t.tn[g].z);
+            d2[4 * g + 3] = fmaf(-2.f, acc[u][4 * g + 3], qq[u] + t.tn[g].w);
+        }
+        float m = fminf(d2[0], d2[1]);
+        for (int e = 2; e < 16; e += 2) m = fminf(m, fminf(d2[e], d2[e + 1]));
+        if (__any(m < thr[u])) {
+            // all 16 wave-wide tests up front (against the threshold before any update: a superset of the hits),
+            // so the scalar unit walks a list of masks instead of waiting for one compare per element
+            u64 hit[16];
+            for (int e = 0; e < 16; ++e) hit[e] = __ballot(d2[e] < thr[u]);
+            for (int e = 0; e < 16; ++e) {
+                if (hit[e]) {
+                    const int tr = t0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const u64 key = d2[e] < thr[u] ? (((u64)__float_as_uint(d2[e]) << 32) | (unsigned)tr) : KEY_NONE;
+                    top2_insert(key, b0[u], b1[u]);
+                    thr[u] = __uint_as_float(min((unsigned)(b1[u] >> 32), 0x7f800000u));
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void knn2_mfma_kernel(const unsigned short *__restrict__ Q, const float *__restrict__ nq,
                                                         const unsigned short *__restrict__ T, const float *__restrict__ nt,
                                                         int n1, int n2, int tiles_per_split,
@@ -117,49 +165,15 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const unsigned short *__
     const int tile1 = min(tile0 + tiles_per_split, n_tiles);
     u64 b0[2] = {KEY_NONE, KEY_NONE}, b1[2] = {KEY_NONE, KEY_NONE};
     float thr[2] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
-    bf16x8 a[8];
-    float4 tn[4];
-    if (tile0 < tile1) {
-        for (int s = 0; s < 8; ++s) a[s] = *(const bf16x8 *)(T + (((int64_t)tile0 * 8 + s) * 64 + lane) * 8);
-        for (int g = 0; g < 4; ++g) tn[g] = *(const float4 *)(nt + tile0 * 32 + 8 * g + 4 * h);
-    }
+    // two tiles in flight in two register sets (no copies); reads past the split's end repeat its last tile
+    TrainTile ta, tb;
+    if (tile0 < tile1) load_train_tile(ta, T, nt, tile0, lane, h);
     if (other_path) return;
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int t0 = tile * 32;
-        const int tp = min(tile + 1, tile1 - 1);          // the last step reads its own tile again
-        bf16x8 an[8];
-        float4 tnn[4];
-        for (int s = 0; s < 8; ++s) an[s] = *(const bf16x8 *)(T + (((int64_t)tp * 8 + s) * 64 + lane) * 8);
-        for (int g = 0; g < 4; ++g) tnn[g] = *(const float4 *)(nt + tp * 32 + 8 * g + 4 * h);
-        f32x16 acc[2];
-        for (int u = 0; u < 2; ++u)
-            for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
-        for (int s = 0; s < 8; ++s)
-            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[u][s], acc[u], 0, 0, 0);
-        for (int u = 0; u < 2; ++u) {
-            float d2[16];
-            for (int g = 0; g < 4; ++g) {
-                d2[4 * g] = fmaf(-2.f, acc[u][4 * g], qq[u] + tn[g].x);
-                d2[4 * g + 1] = fmaf(-2.f, acc[u][4 * g + 1], qq[u] + tn[g].y);
-                d2[4 * g + 2] = fmaf(-2.f, acc[u][4 * g + 2], qq[u] + tn[g].z);
-                d2[4 * g + 3] = fmaf(-2.f, acc[u][4 * g + 3], qq[u] + tn[g].w);
-            }
-            float m = fminf(d2[0], d2[1]);
-            for (int e = 2; e < 16; e += 2) m = fminf(m, fminf(d2[e], d2[e + 1]));
-            if (__any(m < thr[u])) {
-                for (int e = 0; e < 16; ++e) {
-                    const bool take = d2[e] < thr[u];
-                    if (__any(take)) {
-                        const int t = t0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const u64 key = take ? (((u64)__float_as_uint(d2[e]) << 32) | (unsigned)t) : KEY_NONE;
-                        top2_insert(key, b0[u], b1[u]);
-                        thr[u] = __uint_as_float(min((unsigned)(b1[u] >> 32), 0x7f800000u));
-                    }
-                }
-            }
-        }
-        for (int s = 0; s < 8; ++s) a[s] = an[s];
-        for (int g = 0; g < 4; ++g) tn[g] = tnn[g];
+    for (int tile = tile0; tile < tile1; tile += 2) {
+        load_train_tile(tb, T, nt, min(tile + 1, tile1 - 1), lane, h);
+        match_tile(ta, b, qq, tile * 32, h, b0, b1, thr);
+        load_train_tile(ta, T, nt, min(tile + 2, tile1 - 1), lane, h);
+        if (tile + 1 < tile1) match_tile(tb, b, qq, (tile + 1) * 32, h, b0, b1, thr);
     }
     for (int u = 0; u < 2; ++u) {
         const u64 o0 = shfl_xor_u64(b0[u], 32), o1 = shfl_xor_u64(b1[u], 32);
@@ -309,13 +323,15 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
         if (n2) VO_HIP_CHECK(hipMemcpyAsync((void *)d2, des2, b2, hipMemcpyHostToDevice, st));
     }
     const int n1p = div_up(n1, 256) * 256, n2p = div_up(n2 > 0 ? n2 : 1, 64) * 64;
-    // split the train set so that each launch has about a thousand workgroups
+    // split the train set so that each launch fills the device once: 256 CUs x 2 resident workgroups of either kernel
     const int tiles64 = n2p / 64, tiles32 = n2p / 32;
-    int splits = div_up(1024, div_up(n1, 64));
+    int splits = 512 / div_up(n1, 64);
+    if (splits < 1) splits = 1;
     if (splits > tiles64) splits = tiles64;
     const int tiles64_per_split = div_up(tiles64, splits);
     splits = div_up(tiles64, tiles64_per_split);
-    int splits_m = div_up(1024, n1p / 256);
+    int splits_m = 512 / (n1p / 256);
+    if (splits_m < 1) splits_m = 1;
     if (splits_m > tiles32) splits_m = tiles32;
     const int tiles32_per_split = div_up(tiles32, splits_m);
     splits_m = div_up(tiles32, tiles32_per_split);
