@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void desc_pack_kernel(const float *__restrict_
     *(uint4 *)(dst + ((((int64_t)(row >> 5) * 8 + (chunk >> 1)) * 2 + (chunk & 1)) * 32 + (row & 31)) * 8) = o;
     for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
     if ((threadIdx.x & 15) == 0) norm[row] = row < n ? s : pad_norm;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(not_bytes, 1u);
+    // one wavefront raises the flag; the others see it set and skip the atomic (thousands of atomics on one
+    // word took longer than the rest of the kernel).  A stale read only costs a redundant atomic.
+    if (__any(bad) && (threadIdx.x & 63) == 0 && *(volatile unsigned *)not_bytes == 0) atomicOr(not_bytes, 1u);
 }
 
 // Matrix-core path.  A wavefront owns 64 queries (two operands B, held in registers for the
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const unsigned short *__
 
 // General float path: 64 queries x 64 trains per workgroup step, both tiles in LDS with a
 // row pitch of 132 floats (16-byte reads of 16 different rows land in different banks);
-// a lane owns a 4x4 block of pairs and adds the 128 terms of each in ascending k.
+// a lane owns a 4x4 block of pairs and adds the 128 terms of each in ascending k.  The kernel runs at the
+// float32 vector rate (one subtract and one fused multiply-add per term); packed float32 instructions
+// (v_pk_add_f32 / v_pk_fma_f32 over a transposed query tile) were tried and take the same time.
 #define FP 132
 __global__ __launch_bounds__(256) void knn2_f32_kernel(const float *__restrict__ D1, const float *__restrict__ D2, int n1, int n2,
                                                        int tiles_per_split, const unsigned *__restrict__ not_bytes,
