@@ -75,3 +75,22 @@ def test_pnp_inlier_rule(oracle):
     listed = np.zeros(600, bool)
     listed[inl.ravel()] = True
     assert (masks[0].astype(bool) != listed).mean() <= 0.02
+
+
+def test_bf_matcher_knn(oracle):
+    """cv.BFMatcher().knnMatch(des1, des2, k=2) + the ratio test of vo_pipeline/featureMatching.py:58-69.
+    Byte-valued descriptors: every summation order gives the same float32 distance, so equality is exact."""
+    d1, d2, _ = synth.sift_like_descriptors(500, 600, seed=6)
+    ref = cv2.BFMatcher().knnMatch(d1, d2, k=2)
+    idx, dist, keep = oracle.knn_match2(d1, d2, 0.8)
+    assert [[m.trainIdx for m in pair] for pair in ref] == idx.tolist()
+    assert [[m.distance for m in pair] for pair in ref] == dist.tolist()
+    good = [pair[0].queryIdx for pair in ref if pair[0].distance < 0.8 * pair[1].distance]
+    assert good == np.nonzero(keep)[0].tolist()
+    # general float descriptors: OpenCV's SIMD partial sums may differ from the sequential sum in the last bits
+    rng = np.random.default_rng(1)
+    f1, f2 = rng.normal(0, 1, (300, 128)).astype(np.float32), rng.normal(0, 1, (400, 128)).astype(np.float32)
+    ref = cv2.BFMatcher().knnMatch(f1, f2, k=2)
+    idx, dist, _ = oracle.knn_match2(f1, f2, 0.8)
+    assert np.mean(np.array([[m.trainIdx for m in pair] for pair in ref]) == idx) > 0.99
+    np.testing.assert_allclose(np.array([[m.distance for m in pair] for pair in ref]), dist, rtol=1e-5)

@@ -128,3 +128,27 @@ def test_bootstrap_from_descriptors(ctx):
         # descriptors travel with their points
         row = np.nonzero((sc["m1"] == b.pts1[0, :2]).all(1))[0][0]
         assert (b.pts_des1[0] == des0[row]).all() and (b.pts_des2[0] == des1[truth[row]]).all()
+
+
+def test_properties_at_full_size(ctx):
+    """Size-independent checks at 8000 x 8000 (beyond what the CPU checker finishes in seconds): a set matched
+    against itself finds every row at distance 0; shuffling the train rows relabels the matches and leaves
+    the distances bit-identical; both kernels (byte-valued and float input) obey it."""
+    from visual_odometry_amd import hip
+    d1, d2, _ = synth.sift_like_descriptors(8000, 8000, seed=12)
+    rng = np.random.default_rng(0)
+    for scale in (np.float32(1.0), np.float32(1.0 / 512)):       # 1/512 makes the entries non-integers: float kernel
+        a, b = d1 * scale, d2 * scale
+        idx, dist, keep = hip.knn_match2(ctx, a, a, 0.8)
+        # distinct rows in the synthetic set: the nearest neighbour of a row is itself
+        assert (idx[:, 0] == np.arange(8000)).all() and (dist[:, 0] == 0).all() and (dist[:, 1] > 0).all()
+        assert keep.all()
+        idx, dist, keep = hip.knn_match2(ctx, a, b, 0.8)
+        perm = rng.permutation(8000)
+        idx_p, dist_p, keep_p = hip.knn_match2(ctx, a, b[perm], 0.8)
+        assert (dist_p.view(np.uint32) == dist.view(np.uint32)).all() and (keep_p == keep).all()
+        untied = dist[:, 0] != dist[:, 1]
+        assert untied.mean() > 0.99
+        assert (perm[idx_p[untied, 0]] == idx[untied, 0]).all()
+        # the first neighbour is never farther than the second, and both are real rows
+        assert (dist[:, 0] <= dist[:, 1]).all() and (idx >= 0).all() and (idx < 8000).all()
