@@ -36,8 +36,88 @@ def trajectory_error(vo, gt_poses, first):
     return float(np.sqrt(np.mean(err ** 2)) / np.linalg.norm(c_gt[-1])), float(max(rot)), scale
 
 
+def cpu_pnp_ransac(X, x, K, thr, conf, max_iters):
+    """cv.solvePnPRansac(flags=SOLVEPNP_P3P) restated on the CPU the way OpenCV runs it: one sample per
+    iteration, drawn with OpenCV's generator, solved (numpy Grunert P3P, the fourth point picks the root),
+    scored over all points (C oracle), the iteration count adapted after every improvement, and a
+    least-squares refit of the winner on its inliers.  -> (R, t, inlier mask, iterations run)"""
+    from oracle import oracle, solvers_np
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    from visual_odometry_amd.vo_pipeline import ransac
+    X = np.ascontiguousarray(X, np.float32).reshape(-1, 3)
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 2)
+    Kd = np.asarray(K, np.float64).reshape(3, 3)
+    n = X.shape[0]
+    rays = np.linalg.solve(Kd, np.hstack([x.astype(np.float64), np.ones((n, 1))]).T).T
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    Xd = X.astype(np.float64)
+    rng = ransac.CvRNG()
+    niters, it, best, best_Rt, subsets = int(max_iters), 0, 3, None, np.zeros((0, 4), np.int32)
+    while it < niters:
+        if it >= subsets.shape[0]:
+            subsets = np.vstack([subsets, ransac.draw_subsets(rng, n, 4, 32)])
+        sub = subsets[it]
+        it += 1
+        sols = solvers_np.p3p(Xd[sub[:3]], rays[sub[:3]])
+        if not sols:
+            continue
+        def err4(Rt):
+            p = Kd @ (Rt[0] @ Xd[sub[3]] + Rt[1])
+            return np.sum((p[:2] / p[2] - x[sub[3]]) ** 2)
+        R, t = min(sols, key=err4)
+        Rt = np.hstack([R, t.reshape(3, 1)])[None]
+        counts, _ = oracle.score_pnp(X, x, Kd, Rt, thr, want_masks=False)
+        if int(counts[0]) > best:
+            best, best_Rt = int(counts[0]), Rt
+            niters = ransac.ransac_update_num_iters(conf, (n - best) / n, 4, niters)
+    if best_Rt is None:
+        return None, None, np.zeros(n, bool), it
+    _, mask = oracle.score_pnp(X, x, Kd, best_Rt, thr, want_masks=True)
+    inl = mask[0] != 0
+    def res(p):
+        Y = Rotation.from_rotvec(p[:3]).apply(Xd[inl]) + p[3:]
+        return ((Y[:, :2] / Y[:, 2:3]) * [Kd[0, 0], Kd[1, 1]] + [Kd[0, 2], Kd[1, 2]] - x[inl]).ravel()
+    p0 = np.concatenate([Rotation.from_matrix(best_Rt[0][:, :3]).as_rotvec(), best_Rt[0][:, 3]])
+    sol = least_squares(res, p0, method="lm", max_nfev=60)
+    return Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:], inl, it
+
+
+def cpu_frame_baseline(calls, K):
+    """The recorded KLT and PnP calls of tracked frames replayed on one CPU core through the oracle
+    operators; also how far the CPU pose lands from the pose the GPU call returned."""
+    from oracle import oracle
+    t_klt = t_pnp = 0.0
+    rot_diff, trans_diff, iters = [], [], []
+    for c in calls:
+        t0 = time.perf_counter()
+        oracle.klt(c["img0"], c["img1"], c["pts"], win=params.KLT_RADIUS, max_level=params.KLT_NUM_PYRAMIDS,
+                   max_iters=params.KLT_N_ITERS, eps=0.001, min_eig=params.KLT_MIN_EIGEN_THRESHOLD)
+        t1 = time.perf_counter()
+        R, t, inl, it = cpu_pnp_ransac(c["X"], c["x"], K, params.PNP_RANSAC_REPROJ_THRESHOLD, params.PNP_RANSAC_CONFIDENCE,
+                                       params.PNP_RANSAC_MAX_ITERS)
+        t2 = time.perf_counter()
+        t_klt += t1 - t0
+        t_pnp += t2 - t1
+        iters.append(it)
+        if R is not None:
+            dR = R @ c["M"][:3, :3].T
+            rot_diff.append(np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))))
+            trans_diff.append(np.linalg.norm(t - c["M"][:3, 3]) / max(np.linalg.norm(c["M"][:3, 3]), 1e-9))
+    m = len(calls)
+    return {"sample": f"{m} tracked frames of this run (their recorded KLT and PnP inputs), 1 core: C oracle LK with the "
+                      "reference's arguments + OpenCV-style sequential P3P RANSAC (numpy solver, C scoring, adaptive "
+                      "iteration count) + least-squares refit", "cores": 1, "kind": "port",
+            "ms_per_tracked_frame": (t_klt + t_pnp) / m * 1e3, "klt_ms": t_klt / m * 1e3, "pnp_ms": t_pnp / m * 1e3,
+            "frames_per_s": m / (t_klt + t_pnp), "ransac_iterations_mean": float(np.mean(iters)),
+            "max_rotation_diff_deg_vs_gpu_pose": float(max(rot_diff)) if rot_diff else None,
+            "max_rel_translation_diff_vs_gpu_pose": float(max(trans_diff)) if trans_diff else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-baseline", type=int, default=0,
+                    help="replay the KLT and PnP calls of this many tracked frames on the CPU oracle after the run")
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--dataset-params", default="PARKING")
@@ -50,6 +130,25 @@ def main():
     frames = list(data.frames)                   # rendering is not part of the timed loop
     data.frames = iter(frames)
     vo = ContinuousVO(data)
+    calls = []
+    if a.cpu_baseline:
+        from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation
+        klt0, pnp0 = PoseEstimation.KLT, PoseEstimation.PnP
+        last = {}
+
+        def klt_rec(img0, img1, pts, **kw):
+            out = klt0(img0, img1, pts, **kw)
+            last.update(img0=np.array(img0), img1=np.array(img1), pts=np.array(pts, np.float32))
+            return out
+
+        def pnp_rec(self, X, x):
+            M, inl = pnp0(self, X, x)
+            if last and len(calls) < 4 * a.cpu_baseline:
+                calls.append(dict(last, X=np.array(X), x=np.array(x), M=np.array(M)))
+            return M, inl
+
+        PoseEstimation.KLT = staticmethod(klt_rec)
+        PoseEstimation.PnP = pnp_rec
     per_frame = []
     while True:
         t0 = time.perf_counter()
@@ -59,12 +158,16 @@ def main():
     per_frame = np.array(per_frame)
     rel, rot, scale = trajectory_error(vo, np.asarray(data.T, np.float64), vo.frames_to_skip)
     tracked = per_frame[vo.frames_to_skip + 1:]
+    out_cpu = {}
+    if a.cpu_baseline and calls:
+        step = max(1, len(calls) // a.cpu_baseline)
+        out_cpu = {"cpu_baseline": cpu_frame_baseline(calls[::step][:a.cpu_baseline], np.asarray(data.K, np.float64))}
     print(json.dumps({"frames": len(per_frame), "keyframes": [k.idx for k in vo.keyframes],
                       "loop_frames_per_s": float(len(tracked) / tracked.sum()),
                       "median_ms_per_tracked_frame": float(np.median(tracked) * 1e3),
                       "bootstrap_ms": float(per_frame[vo.frames_to_skip] * 1e3),
                       "rel_position_rms": rel, "max_rotation_deg": rot, "scale": scale,
-                      "landmarks": len(vo.keypoint_trajectories.landmarks)}))
+                      "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu}))
 
 
 if __name__ == "__main__":
