@@ -269,6 +269,22 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, in
                                int max_iters, uint64_t *rng_state, double *F_out, uint8_t *inlier_mask,
                                int32_t *n_inliers);
 
+/* ---- corner mask and sub-pixel refinement of FeatureExtractor.harris -------------------------
+ * vo_harris_mask replaces cv.cornerHarris + cv.dilate + cv.threshold + np.uint8
+ * (vo_pipeline/featureExtraction.py:40-43): mask = 255 where the 3x3 maximum of the response
+ * (pixels outside the image ignored) exceeds (float)(rel_thresh * max response), else 0.
+ * img as in vo_harris_response; mask (batch, height, width) uint8, tight.
+ * vo_corner_subpix replaces cv.cornerSubPix(img, corners, (win_w, win_h), (-1,-1),
+ * (EPS + MAX_ITER, max_iters, eps)) (featureExtraction.py:47-50) on one grayscale uint8 image
+ * (the reference converts it to float32, which holds the same values): corners (count,2)
+ * float32 (x, y) are refined in place.  Windows that leave the image sample with coordinates
+ * clamped to the border.  Half-sizes up to 6.
+ */
+int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
+                   int64_t img_stride, float k, int mode, double rel_thresh, uint8_t *mask, int mem);
+int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, float *corners,
+                     int count, int win_w, int win_h, int max_iters, double eps, int mem);
+
 /* ---- descriptor matching -----------------------------------------------------------------
  * vo_knn_match2 replaces matcher.knnMatch(des1, des2, k=2) inside
  * FeatureMatcher.match_descriptors (vo_pipeline/featureMatching.py:52-63) and the ratio test

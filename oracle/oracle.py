@@ -33,6 +33,7 @@ def lib():
         _declare_more(_lib)
         _declare_harris(_lib)
         _declare_match(_lib)
+        _declare_subpix(_lib)
     return _lib
 
 
@@ -79,6 +80,14 @@ def _declare_harris(L):
     L.vo_or_harris_response.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _f32p]
     L.vo_or_nms_topk.restype = ctypes.c_int
     L.vo_or_nms_topk.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _f32p, _f32p]
+
+
+def _declare_subpix(L):
+    L.vo_or_harris_mask.restype = None
+    L.vo_or_harris_mask.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_double, _u8p]
+    L.vo_or_corner_subpix.restype = None
+    L.vo_or_corner_subpix.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _f32p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_double]
 
 
 def _declare_match(L):
@@ -236,3 +245,22 @@ def knn_match2(des1, des2, ratio=0.8):
     lib().vo_or_knn_match2(_p(a, _f32p), n1, _p(b, _f32p), n2, int(dim), float(ratio), _p(idx, _i32p), _p(dist, _f32p),
                            _p(keep, _u8p))
     return idx, dist, keep
+
+
+def harris_mask(img, k=0.1, rel_thresh=0.01, mode=0):
+    """cornerHarris + dilate + threshold + uint8 of FeatureExtractor.harris -> (H,W) uint8 in {0,255}."""
+    R = harris_response(img, k, mode)
+    h, w = R.shape
+    mask = np.empty((h, w), np.uint8)
+    lib().vo_or_harris_mask(_p(R, _f32p), h, w, float(rel_thresh), _p(mask, _u8p))
+    return mask
+
+
+def corner_subpix(img, corners, win=(5, 5), max_iters=50, eps=0.001):
+    """cv.cornerSubPix restatement on a uint8 image -> refined (M,2) float32 copy."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.array(corners, np.float32).reshape(-1, 2).copy()
+    h, w = img.shape
+    lib().vo_or_corner_subpix(_p(img, _u8p), h, w, w, _p(out, _f32p), out.shape[0], int(win[0]), int(win[1]), int(max_iters),
+                              float(eps))
+    return out

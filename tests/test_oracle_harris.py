@@ -58,3 +58,46 @@ def test_harris_finds_planted_corners(oracle):
     corners = {(30, 20), (69, 20), (30, 49), (69, 49)}
     for x, y in xy:
         assert min(abs(x - cx) + abs(y - cy) for cx, cy in corners) <= 2
+
+
+def test_mask_against_ndimage(oracle):
+    """dilate + threshold of the oracle against scipy.ndimage's maximum filter."""
+    from scipy import ndimage
+    from visual_odometry_amd import synth
+    img = synth.frame_pair((90, 140), seed=5)[0]
+    R = oracle.harris_response(img, 0.1, 0)
+    dil = ndimage.maximum_filter(R, size=3, mode="constant", cval=-np.inf)
+    thr = np.float32(0.01 * np.float64(R.max()))
+    assert (oracle.harris_mask(img) == np.where(dil > thr, 255, 0)).all()
+
+
+def test_subpix_known_answer(oracle):
+    """Blurred checkerboard: corners started up to 2 px off land within 0.05 px (median) of the true
+    saddle points; a point in a flat region stays where it is; a result beyond the window is discarded."""
+    from scipy import ndimage
+    yy, xx = np.mgrid[0:120, 0:160]
+    img = np.where(((yy // 20) + (xx // 20)) % 2 == 0, 50, 200).astype(np.float64)
+    img = np.clip(np.rint(ndimage.gaussian_filter(img, 1.0)), 0, 255).astype(np.uint8)
+    true = np.array([(x - 0.5, y - 0.5) for y in range(20, 120, 20) for x in range(20, 160, 20)], np.float32)
+    start = (true + np.random.default_rng(1).uniform(-2, 2, true.shape)).astype(np.float32)
+    got = oracle.corner_subpix(img, start)
+    err = np.linalg.norm(got - true, axis=1)
+    assert np.median(err) < 0.05 and err.max() < 0.2
+    flat = np.array([[10.0, 10.0]], np.float32)
+    assert (oracle.corner_subpix(img, flat) == flat).all()
+    # the exact float64 solution of the same weighted system, built independently, for one interior corner
+    p = start[:1]
+    one = oracle.corner_subpix(img, p, (5, 5), 1, 0.0)
+    f = img.astype(np.float64)
+    gx_full = ndimage.map_coordinates
+    ys, xs = np.mgrid[-6:7, -6:7].astype(np.float64)
+    patch = gx_full(f, [ys + p[0, 1], xs + p[0, 0]], order=1, mode="nearest")
+    tgx = patch[1:-1, 2:] - patch[1:-1, :-2]
+    tgy = patch[2:, 1:-1] - patch[:-2, 1:-1]
+    g = np.exp(-(np.arange(-5, 6) / 5.0) ** 2)
+    m = np.outer(g, g)
+    py, px = np.mgrid[-5:6, -5:6].astype(np.float64)
+    G = np.array([[np.sum(tgx * tgx * m), np.sum(tgx * tgy * m)], [np.sum(tgx * tgy * m), np.sum(tgy * tgy * m)]])
+    bb = np.array([np.sum((tgx * tgx * px + tgx * tgy * py) * m), np.sum((tgx * tgy * px + tgy * tgy * py) * m)])
+    expect = p[0] + np.linalg.solve(G, bb)
+    assert np.abs(one[0] - expect).max() < 2e-3

@@ -81,6 +81,10 @@ SIGNATURES = {
                                                   ctypes.POINTER(ctypes.c_int32)]),
     "vo_refine_pose": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p,
                                       ctypes.c_int]),
+    "vo_harris_mask": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_float, ctypes.c_int, ctypes.c_double, c_vp, ctypes.c_int]),
+    "vo_corner_subpix": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
     "vo_knn_match2": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp, c_vp,
                                      c_vp, ctypes.c_int]),
 }

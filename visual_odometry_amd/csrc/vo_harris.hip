@@ -698,3 +698,71 @@ extern "C" int vo_detect_corners(vo_ctx *ctx, const uint8_t *img, int batch, int
     if (mem == VO_MEM_HOST) return corners_copy_out(ctx, batch, K, d_xy, d_sc, d_cnt, xy, scores, count);
     return VO_OK;
 }
+
+// ---- corner mask of FeatureExtractor.harris ---------------------------------------------------
+// mask = (3x3 maximum of R, pixels outside the image ignored) > (float)(rel_thresh * max R):
+// cv.dilate + cv.threshold of vo_pipeline/featureExtraction.py:41-42 in one pass over R.
+__global__ __launch_bounds__(256) void harris_mask_kernel(const float *__restrict__ R, int w, int h, double rel_thresh,
+                                                          const uint32_t *__restrict__ maxkey, uint8_t *__restrict__ mask)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const float thr = (float)(rel_thresh * (double)key_value(maxkey[b * MAXKEY_STRIDE]));
+    const float *img = R + (size_t)b * w * h;
+    float m = img[(size_t)y * w + x];
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            m = fmaxf(m, img[(size_t)yy * w + xx]);
+        }
+    mask[(size_t)b * w * h + (size_t)y * w + x] = m > thr ? 255 : 0;
+}
+
+extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
+                              int64_t img_stride, float k, int mode, double rel_thresh, uint8_t *mask, int mem)
+{
+    VO_REQUIRE(ctx && img && mask, "vo_harris_mask: NULL argument");
+    VO_REQUIRE(batch >= 1 && batch <= 65535 && height >= 3 && width >= 3, "vo_harris_mask: bad shape batch=%d h=%d w=%d", batch, height, width);
+    VO_REQUIRE((int64_t)height * width < (1ll << 31), "vo_harris_mask: image too large");
+    VO_REQUIRE(mode == 0 || mode == 1, "vo_harris_mask: mode %d (0 = Harris, 1 = min eigenvalue)", mode);
+    VO_REQUIRE(row_stride >= width && (batch == 1 || img_stride >= row_stride * height), "vo_harris_mask: bad strides");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_harris_mask: bad mem flag %d", mem);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc;
+    void *p;
+    const size_t npix = (size_t)width * height;
+    const uint8_t *d_img = img;
+    uint8_t *d_mask = mask;
+    int64_t pitch = row_stride, istride = img_stride;
+    if (mem == VO_MEM_HOST) {
+        if ((rc = vo_stage_reserve(ctx, 0, npix * batch, &p))) return rc; d_img = (const uint8_t *)p;
+        if ((rc = vo_stage_reserve(ctx, 2, npix * batch, &p))) return rc; d_mask = (uint8_t *)p;
+        if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
+            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            for (int b = 0; b < batch; ++b)
+                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
+                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+        }
+        pitch = width; istride = (int64_t)npix;
+    }
+    if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc;     // library-owned response map
+    float *d_R = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
+    uint32_t *d_max = (uint32_t *)p;
+    VO_HIP_CHECK(hipMemsetAsync(d_max, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
+    dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);
+    VO_REQUIRE(grid.y <= 65535u, "vo_harris_mask: image too tall");
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
+                       d_max);
+    dim3 mgrid((width + 63) / 64, (height + 3) / 4, batch);
+    VO_REQUIRE(mgrid.y <= 65535u, "vo_harris_mask: image too tall");
+    hipLaunchKernelGGL(harris_mask_kernel, mgrid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh, d_max, d_mask);
+    VO_HIP_CHECK(hipGetLastError());
+    if (mem == VO_MEM_HOST) {
+        VO_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npix * batch, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}

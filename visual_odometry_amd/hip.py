@@ -464,6 +464,53 @@ def triangulate(ctx: Context, pts1, pts2, M1, M2):
     return out
 
 
+def harris_mask(ctx: Context, imgs, k: float = 0.1, rel_thresh: float = 0.01, mode: int = HARRIS):
+    """255 where the 3x3 maximum of the corner response exceeds rel_thresh * its image maximum, else 0:
+    cornerHarris + dilate + threshold + uint8 of the reference's FeatureExtractor.harris.  imgs: (B,H,W) or
+    (H,W) uint8, numpy or torch -> mask of the same shape and kind."""
+    single = imgs.ndim == 2
+    if _is_torch(imgs):
+        import torch
+        a = imgs if not single else imgs[None]
+        if a.dtype != torch.uint8 or a.stride(-1) != 1:
+            raise ValueError("harris_mask: device images must be uint8 with unit pixel stride")
+        B, H, W = a.shape
+        rs, ist = a.stride(1), (a.stride(0) if B > 1 else a.stride(1) * H)
+        mask = torch.empty((B, H, W), dtype=torch.uint8, device=a.device)
+        mem = VO_MEM_DEVICE
+    else:
+        a = np.ascontiguousarray(imgs, np.uint8)
+        a = a if not single else a[None]
+        B, H, W = a.shape
+        rs, ist = W, W * H
+        mask = np.empty((B, H, W), np.uint8)
+        mem = VO_MEM_HOST
+    check(ctx.lib.vo_harris_mask(ctx.handle, _ptr(a), int(B), int(H), int(W), int(rs), int(ist), float(k), int(mode),
+                                 float(rel_thresh), _ptr(mask), mem), "vo_harris_mask")
+    return mask[0] if single else mask
+
+
+def corner_subpix(ctx: Context, img, corners, win=(5, 5), max_iters: int = 50, eps: float = 0.001):
+    """cv.cornerSubPix on one grayscale uint8 image: corners (M,2) float32 (x, y) -> refined copy."""
+    if _is_torch(img):
+        import torch
+        if not _is_torch(corners) or img.dtype != torch.uint8 or img.stride(-1) != 1 or corners.dtype != torch.float32:
+            raise ValueError("corner_subpix: device arguments must be a uint8 image and float32 corners")
+        H, W = img.shape
+        rs = img.stride(0)
+        out = corners.reshape(-1, 2).contiguous().clone()
+        mem = VO_MEM_DEVICE
+    else:
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        rs = W
+        out = np.array(corners, np.float32).reshape(-1, 2).copy()
+        mem = VO_MEM_HOST
+    check(ctx.lib.vo_corner_subpix(ctx.handle, _ptr(img), int(H), int(W), int(rs), _ptr(out), int(out.shape[0]), int(win[0]),
+                                   int(win[1]), int(max_iters), float(eps), mem), "vo_corner_subpix")
+    return out
+
+
 def knn_match2(ctx: Context, des1, des2, ratio: float = 0.8):
     """Two nearest rows of des2 (n2,128) for every row of des1 (n1,128), exhaustive float32 L2 search.
     Returns (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8); keep = dist[:,0] < ratio * dist[:,1].

@@ -36,14 +36,30 @@ class FeatureExtractor:
 
     @staticmethod
     def harris(img: np.ndarray) -> np.ndarray:
-        """Harris corners with the reference's parameters (blockSize 2, ksize 3, k = 0.1,
-        threshold 0.01 * max; featureExtraction.py:37-51) -> (M, 2) float32 (x, y).
+        """Harris corners as the reference computes them (featureExtraction.py:37-51) -> (M, 2) float32 (x, y):
+        response with blockSize 2, ksize 3, k = 0.1; 3x3 dilation; threshold at 0.01 * max; 8-connected
+        components of the mask; their centroids -- row 0 is the centroid of the background, as in the
+        reference, whose connectedComponentsWithStats call returns label 0 first --; cornerSubPix with an
+        11x11 window, at most 50 iterations, eps 1e-3.  Response, mask and refinement run on the GPU
+        (vo_harris_mask, vo_corner_subpix); the labelling of the mask, a host step between them, uses
+        scipy.ndimage.label, which numbers the components in raster order of their first pixel."""
+        from scipy import ndimage
+        ctx = _runtime.context()
+        gray = np.ascontiguousarray(img, dtype=np.uint8)
+        mask = hip.harris_mask(ctx, gray, 0.1, 0.01, hip.HARRIS)
+        labels, n = ndimage.label(mask, structure=np.ones((3, 3), np.int32))
+        flat = labels.ravel()
+        area = np.bincount(flat, minlength=n + 1).astype(np.float64)
+        ys, xs = np.divmod(np.arange(flat.size), gray.shape[1])
+        cx = np.bincount(flat, weights=xs, minlength=n + 1) / np.maximum(area, 1)
+        cy = np.bincount(flat, weights=ys, minlength=n + 1) / np.maximum(area, 1)
+        centroids = np.stack([cx, cy], axis=1)
+        return hip.corner_subpix(ctx, gray, np.float32(centroids), (5, 5), 50, 0.001)
 
-        The response is cv.cornerHarris' arithmetic; where the reference dilates,
-        labels connected components and refines their centroids with cornerSubPix
-        (returning the background blob's centroid as row 0), this returns the integer
-        positions of the 3x3 local maxima above the same threshold, strongest first
-        (at most 4096)."""
+    @staticmethod
+    def harris_maxima(img: np.ndarray) -> np.ndarray:
+        """Integer positions of the 3x3 local maxima of the same Harris response above the same threshold,
+        strongest first (at most 4096), all on the GPU -> (M, 2) float32 (x, y)."""
         ctx = _runtime.context()
         xy, _, cnt = hip.detect_corners(ctx, np.ascontiguousarray(img, dtype=np.uint8), 4096, 0.01, 1, 0.1, hip.HARRIS)
         return xy[0, :int(cnt[0])]
