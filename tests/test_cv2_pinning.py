@@ -94,3 +94,23 @@ def test_bf_matcher_knn(oracle):
     idx, dist, _ = oracle.knn_match2(f1, f2, 0.8)
     assert np.mean(np.array([[m.trainIdx for m in pair] for pair in ref]) == idx) > 0.99
     np.testing.assert_allclose(np.array([[m.distance for m in pair] for pair in ref]), dist, rtol=1e-5)
+
+
+def test_harris_mask_and_corner_subpix(oracle):
+    """The tail of FeatureExtractor.harris with the reference's own calls (featureExtraction.py:39-50)."""
+    img = synth.frame_pair((240, 320), seed=9)[0]
+    f = np.float32(img)
+    dst = cv2.cornerHarris(f, 2, 3, 0.1)
+    dst = cv2.dilate(dst, None)
+    _, dst = cv2.threshold(dst, 0.01 * dst.max(), 255, 0)
+    ref_mask = np.uint8(dst)
+    got_mask = oracle.harris_mask(img)
+    assert (got_mask == ref_mask).mean() > 0.999          # the response itself is compared in test_corner_response
+    _, _, _, centroids = cv2.connectedComponentsWithStats(ref_mask)
+    criteria = (cv2.TERM_CRITERIA_EPS + cv2.TERM_CRITERIA_MAX_ITER, 50, 0.001)
+    start = np.float32(centroids)
+    ref = cv2.cornerSubPix(f, start.copy(), (5, 5), (-1, -1), criteria)
+    got = oracle.corner_subpix(img, start, (5, 5), 50, 0.001)
+    inner = (start[:, 0] > 8) & (start[:, 0] < 311) & (start[:, 1] > 8) & (start[:, 1] < 231)
+    assert np.abs(got[inner] - ref[inner]).max() < 1e-3   # interior windows: same arithmetic
+    assert np.abs(got - ref).max() < 0.05                 # border windows sample clamped coordinates

@@ -56,6 +56,7 @@ def main():
         "TrackPoints.trackKLT ms (forward+backward)": t(lambda: tp.trackKLT(img0, img1, pts)),
         "PoseEstimation.PnP ms (2000 points, 100 RANSAC iterations + refit)": t(lambda: pe.PnP(sc["X"], sc["m2"]), reps=10),
         "findFundamentalMat ms (2000 points, 100 iterations)": t(lambda: BootstrapInitializer.findFundamentalMat(sc["m1"], sc["m2"], 0.1, 0.9999, 100), reps=10),
+        "FeatureExtractor.harris ms (1241x376: mask on the GPU, labelling on the host, cornerSubPix on the GPU)": t(lambda: FeatureExtractor.harris(img0), reps=10),
         "FeatureExtractor.corners ms (top-2000)": t(lambda: FeatureExtractor.corners(img0, 2000)),
         "BootstrapInitializer._linear_triangulation ms (2000 pairs)": t(lambda: BootstrapInitializer._linear_triangulation(p1, p2, M1, M2)),
         "FeatureMatcher.match_descriptors ms (3000 x 3000 descriptors, list of DMatch objects)": t(lambda: fm.match_descriptors(des0, des1)),

@@ -48,12 +48,18 @@ class FeatureExtractor:
         gray = np.ascontiguousarray(img, dtype=np.uint8)
         mask = hip.harris_mask(ctx, gray, 0.1, 0.01, hip.HARRIS)
         labels, n = ndimage.label(mask, structure=np.ones((3, 3), np.int32))
-        flat = labels.ravel()
-        area = np.bincount(flat, minlength=n + 1).astype(np.float64)
-        ys, xs = np.divmod(np.arange(flat.size), gray.shape[1])
-        cx = np.bincount(flat, weights=xs, minlength=n + 1) / np.maximum(area, 1)
-        cy = np.bincount(flat, weights=ys, minlength=n + 1) / np.maximum(area, 1)
-        centroids = np.stack([cx, cy], axis=1)
+        # centroids from the foreground pixels only; the background's (label 0, first row as in the reference)
+        # follows from the totals over the whole image
+        h, w = gray.shape
+        ys, xs = np.nonzero(labels)
+        lab = labels[ys, xs]
+        area = np.bincount(lab, minlength=n + 1).astype(np.float64)
+        sx = np.bincount(lab, weights=xs, minlength=n + 1)
+        sy = np.bincount(lab, weights=ys, minlength=n + 1)
+        area[0] = h * w - ys.size
+        sx[0] = w * (w - 1) / 2.0 * h - xs.sum(dtype=np.float64)
+        sy[0] = h * (h - 1) / 2.0 * w - ys.sum(dtype=np.float64)
+        centroids = np.stack([sx, sy], axis=1) / np.maximum(area, 1)[:, None]
         return hip.corner_subpix(ctx, gray, np.float32(centroids), (5, 5), 50, 0.001)
 
     @staticmethod
