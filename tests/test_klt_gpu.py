@@ -183,3 +183,16 @@ def test_bad_arguments(ctx):
         hip.klt_track(ctx, p, q, np.zeros((4, 2), np.float32))   # p not built
     with pytest.raises(ValueError):
         p.build(np.zeros((32, 64), np.uint8))
+
+
+def test_klt_negative_fourth_weight(oracle, ctx, klt_kernel):
+    """Fractional offsets within ~3e-5 of an integer in one axis make all three rounded bilinear weights round
+    up, so the fourth, 2^14 - iw00 - iw01 - iw10, is -1 (OpenCV keeps it as a signed int).  Such keypoints
+    must track like their neighbours (a kernel that reads the weights as unsigned lanes sends them 100 px off)."""
+    img0, img1, _ = synth.frame_pair((365, 615), seed=102, max_shift=7.0463036954220915)
+    base = np.array([(380.49796, 220.00018), (100.12449, 60.000045), (200.00004, 150.3), (301.62, 99.99997),
+                     (150.000045, 180.000045)], np.float32)
+    pts = np.vstack([base, base * 2 % np.array([600, 350], np.float32) + 8, base + 0.25]).astype(np.float32)
+    for ml in (0, 2, 8):
+        agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=ml)
+        assert agree == 1.0 and n_both >= 12 and d <= POS_TOL, (ml, agree, d)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Seed/shape sweep of every GPU operator against the CPU oracle, beyond the fixed cases of tests/.
+Prints one JSON line per operator with the worst deviation seen; exits non-zero at the first breach
+of the parity bars (bit-exact integer/byte/index work and float32 maps; LK positions 0.05 px with
+>= 99.5 % status agreement)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=12)
+    a = ap.parse_args()
+    from oracle import oracle
+    from visual_odometry_amd import hip, synth
+    ctx = hip.Context(0)
+    rng = np.random.default_rng(1234)
+    worst = {"klt_px": 0.0, "klt_status": 1.0, "klt_points": 0}
+    for seed in range(a.seeds):
+        h, w = int(rng.integers(60, 400)), int(rng.integers(80, 700))
+        img0, img1, _ = synth.frame_pair((h, w), seed=100 + seed, max_shift=float(rng.uniform(1, 8)))
+        # pyramid
+        pyr = hip.Pyramid(ctx, 1, h, w, 8).build(img0)
+        for lvl in range(pyr.max_level + 1):
+            assert (pyr.download(0, lvl) == oracle.pyr_level(img0, lvl)).all(), ("pyramid", seed, lvl)
+        # LK, both kernels
+        n = int(rng.integers(50, 1500))
+        pts = synth.uniform_keypoints((h, w), n, seed=seed, margin=int(rng.integers(0, 12)))
+        ro, rs, _ = oracle.klt(img0, img1, pts, max_level=8)
+        for variant in ("1", "3"):
+            os.environ["VO_KLT_VARIANT"] = variant
+            p1 = hip.Pyramid(ctx, 1, h, w, 8).build(img1)
+            out, st, _ = hip.klt_track(ctx, pyr, p1, pts)
+            agree = float((st[0] == rs.ravel()).mean())
+            both = (st[0] == 1) & (rs.ravel() == 1)
+            d = float(np.abs(out[0][both] - ro[both]).max()) if both.any() else 0.0
+            worst["klt_px"] = max(worst["klt_px"], d)
+            worst["klt_status"] = min(worst["klt_status"], agree)
+            worst["klt_points"] += n
+            assert d <= 0.05 and agree >= 0.995, ("klt", seed, variant, d, agree)
+        os.environ.pop("VO_KLT_VARIANT", None)
+        # corner response, NMS/top-K, mask, sub-pixel refinement
+        for mode in (hip.HARRIS, hip.MIN_EIGEN):
+            k = float(rng.choice([0.04, 0.1]))
+            R = hip.harris_response(ctx, img0[None], k, mode)[0]
+            Ro = oracle.harris_response(img0, k, mode)
+            assert (R.view(np.uint32) == Ro.view(np.uint32)).all(), ("response", seed, mode)
+            radius, K = int(rng.integers(1, 12)), int(rng.integers(10, 3000))
+            xy, sc, cnt = hip.detect_corners(ctx, img0[None], K, 0.01, radius, k, mode)
+            oxy, osc, om = oracle.nms_topk(Ro, K, 0.01, radius)
+            assert int(cnt[0]) == om and (xy[0, :om] == oxy[:om]).all() and (sc[0, :om] == osc[:om]).all(), ("corners", seed, mode, radius, K)
+            assert (hip.harris_mask(ctx, img0, k, 0.01, mode) == oracle.harris_mask(img0, k, 0.01, mode)).all(), ("mask", seed)
+    print(json.dumps({"op": "pyramid/klt/corners/mask", "seeds": a.seeds, **worst}), flush=True)
+    # sub-pixel refinement, own loop so that both sides get identical arguments
+    for seed in range(a.seeds):
+        h, w = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+        img = synth.frame_pair((h, w), seed=300 + seed)[0]
+        pts = synth.uniform_keypoints((h, w), int(rng.integers(1, 800)), seed=seed, margin=0)
+        win, iters = (int(rng.integers(1, 7)), int(rng.integers(1, 7))), int(rng.integers(1, 60))
+        got = hip.corner_subpix(ctx, img, pts, win, iters, 0.001)
+        ref = oracle.corner_subpix(img, pts, win, iters, 0.001)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), ("subpix", seed, win, iters)
+    print(json.dumps({"op": "corner_subpix", "seeds": a.seeds, "bit_exact": True}), flush=True)
+    # scoring and minimal-solver pipelines
+    for seed in range(a.seeds):
+        n, H = int(rng.integers(20, 4000)), int(rng.integers(1, 600))
+        sc = synth.two_view_scene(n=n, seed=seed, inlier_frac=float(rng.uniform(0.3, 1.0)), noise=float(rng.uniform(0, 1)))
+        Fh, Rt = synth.fundamental_hypotheses(sc, H, seed=seed), synth.pose_hypotheses(sc, H, seed=seed)
+        thr = float(rng.uniform(0.05, 2.0))
+        c, m = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh, thr)
+        oc, om = oracle.score_fundamental(sc["m1"], sc["m2"], Fh, thr)
+        assert (c == oc).all() and (m == om).all(), ("score_f", seed)
+        c, m = hip.score_pnp(ctx, sc["X"], sc["m2"], sc["K"], Rt, thr)
+        oc, om = oracle.score_pnp(sc["X"], sc["m2"], sc["K"], Rt, thr)
+        assert (c == oc).all() and (m == om).all(), ("score_pnp", seed)
+    print(json.dumps({"op": "score_fundamental/score_pnp", "seeds": a.seeds, "bit_exact": True}), flush=True)
+    # BA residual / normal equations
+    worst_ba = 0.0
+    for seed in range(a.seeds):
+        F, P = int(rng.integers(2, 24)), int(rng.integers(5, 3000))
+        pb = synth.ba_problem(F=F, P=P, visibility=float(rng.uniform(0.3, 1.0)), seed=seed)
+        start = int(np.count_nonzero(pb["ci"] < int(F / 4) + 1))
+        got = hip.ba_normal_eq(ctx, pb["x"], F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], start)
+        ref = oracle.ba_normal_eq(pb["x"], F, P, pb["ci"], pb["pi"], pb["obs"], pb["K"], start)
+        for key in ("r", "cost", "Hcc", "Hpp", "Hcp", "g"):
+            g, r = np.asarray(got[key], np.float64), np.asarray(ref[key], np.float64)
+            scale = max(np.abs(r).max(), 1e-300)
+            worst_ba = max(worst_ba, float(np.abs(g - r).max() / scale))
+        assert worst_ba < 1e-9, ("ba", seed, worst_ba)
+    print(json.dumps({"op": "ba_normal_eq", "seeds": a.seeds, "max_rel_dev": worst_ba}), flush=True)
+    # descriptor matching, both kernels
+    for seed in range(a.seeds):
+        n1, n2 = int(rng.integers(1, 2500)), int(rng.integers(2, 2500))
+        d1, d2, _ = synth.sift_like_descriptors(n1, n2, shared=float(rng.uniform(0, 1)), seed=seed)
+        for scale in (np.float32(1), np.float32(rng.uniform(0.001, 3.0))):
+            x, y = d1 * scale, d2 * scale
+            ratio = float(rng.uniform(0.5, 1.0))
+            gi, gd, gk = hip.knn_match2(ctx, x, y, ratio)
+            ri, rd, rk = oracle.knn_match2(x, y, ratio)
+            assert (gi == ri).all() and (gd.view(np.uint32) == rd.view(np.uint32)).all() and (gk == rk).all(), ("match", seed, n1, n2)
+    print(json.dumps({"op": "knn_match2", "seeds": a.seeds, "bit_exact": True}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

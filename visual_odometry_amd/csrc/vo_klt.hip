@@ -12,7 +12,7 @@
 // its template values (I, Ix, Iy) stay in registers for the whole level.
 // Per wave the kernel stages in LDS
 //   * the 24x24 previous-image tile as 16-bit pixel pairs {p[x], p[x+1]} (ready
-//     for v_dot2_u32_u16 against the packed bilinear weights); the Scharr
+//     for v_dot2_i32_i16 against the packed bilinear weights); the Scharr
 //     derivatives are formed from it in registers with packed 16-bit math, two
 //     window columns per instruction, and never touch memory;
 //   * a (22+2M)x(21+2M) tile of the next image around the current estimate,
@@ -139,9 +139,23 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wt,
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Pixel pair . weight pair + c.  The product is SIGNED: the fourth weight 2^14 - iw00 - iw01 - iw10 is -1 when
+// all three roundings go up (a fractional offset within ~3e-5 of an integer), and an unsigned 16-bit lane
+// would read that -1 as 65535.  Pixels (<= 255) and the other weights (<= 2^14) are the same in both readings.
+// Three-operand encoding written out: from the builtin the compiler picks the accumulate-in-place form
+// plus a move for every accumulator that has to survive (the per-sample 256 - 512 I seeds do): +5 % kernel time.
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), c, false);
+    uint32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the same with a wave-uniform addend, which then needs no vector register
+__device__ __forceinline__ uint32_t udot2_s(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
 }
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 {
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
             }
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                const int ival = (int)(udot2(pr[k], wt, udot2(pr[k + 1], wb, 1u << 8)) >> 9);
+                const int ival = (int)(udot2(pr[k], wt, udot2_s(pr[k + 1], wb, 1u << 8)) >> 9);
                 const int ixval = sdot2(dxp[k], wtd, sdot2(dxp[k + 1], wbd, 1 << 13)) >> 14;
                 const int iyval = sdot2(dyp[k], wtd, sdot2(dyp[k + 1], wbd, 1 << 13)) >> 14;
                 Ic[k] = 256u - ((uint32_t)ival << 9);
@@ -511,7 +525,7 @@ __device__ __forceinline__ void k3_template(const uint32_t *t, uint32_t wt, uint
             const uint32_t pr_k = prev_centre;   // centre pairs of tile row k + 1
             if (k >= 1) {
                 const int j = k - 1;
-                const uint32_t si = udot2(pr_k1, wt, udot2(pr_k, wb, 1u << 8));   // 512 * I + rounding bits
+                const uint32_t si = udot2(pr_k1, wt, udot2_s(pr_k, wb, 1u << 8));   // 512 * I + rounding bits
                 const int ixd = sdot2(dx_k1, wtd, sdot2_keep(dx, wbd, bias));     // Ix << 14
                 const int iyd = sdot2(dy_k1, wtd, sdot2_keep(dy, wbd, bias));
                 Ic[j] = 256u - (si & ~0x1ffu);
