@@ -196,3 +196,34 @@ def test_klt_negative_fourth_weight(oracle, ctx, klt_kernel):
     for ml in (0, 2, 8):
         agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=ml)
         assert agree == 1.0 and n_both >= 12 and d <= POS_TOL, (ml, agree, d)
+
+
+def test_bench_workload_parity(oracle, ctx):
+    """The benchmark's own workload: 64 KITTI-shaped streams of 2000 keypoints tracked in one launch from
+    device-resident frames (4-level pyramid, maxLevel 3); three of the streams against the oracle."""
+    import os
+    import sys
+    import torch
+    from visual_odometry_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    distinct = 8                                             # eight seeded streams, repeated to fill the launch
+    frames, pts = bench.make_streams(list(range(distinct)), 2)
+    S = 64
+    f = np.tile(frames, (1, S // distinct, 1, 1))
+    p = np.tile(pts, (S // distinct, 1, 1))
+    tctx = hip.Context.from_torch(0)
+    d0, d1 = torch.from_numpy(f[0].copy()).cuda(), torch.from_numpy(f[1].copy()).cuda()
+    pyr0 = hip.Pyramid(tctx, S, bench.H, bench.W, bench.MAX_LEVEL).build(d0)
+    pyr1 = hip.Pyramid(tctx, S, bench.H, bench.W, bench.MAX_LEVEL).build(d1)
+    out, st, err = hip.klt_track(tctx, pyr0, pyr1, torch.from_numpy(p.copy()).cuda())
+    tctx.sync()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    # copies of one stream give identical results wherever they sit in the launch
+    for s in range(distinct, S):
+        assert (out[s] == out[s % distinct]).all() and (st[s] == st[s % distinct]).all()
+    for s in (0, 3, 7):
+        ro, rs, _ = oracle.klt(frames[0, s], frames[1, s], pts[s], max_level=bench.MAX_LEVEL)
+        assert (st[s] == rs.ravel()).mean() >= STATUS_AGREE
+        both = (st[s] == 1) & (rs.ravel() == 1)
+        assert both.mean() > 0.99 and np.abs(out[s][both] - ro[both]).max() <= POS_TOL
