@@ -73,8 +73,7 @@ int vo_pyr_download(vo_ctx *ctx, const vo_pyr *pyr, int image, int level, uint8_
  * (x, y); image b of `prev` is tracked into image b of `next`.
  * init_pts may be NULL (start at prev_pts, as the reference does).
  * status: (batch, n) uint8, 1 = tracked.  err: (batch, n) float32 min-eigenvalue,
- * may be NULL.  Every pyramid level must be at least 23 pixels wide and high (a level of
- * exactly 22, which OpenCV's level rule admits, is rejected with VO_EINVAL).
+ * may be NULL.
  */
 typedef struct vo_klt_params {
     int max_iters;     /* criteria count (clamped to [0,100]) */

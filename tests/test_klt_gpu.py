@@ -227,3 +227,13 @@ def test_bench_workload_parity(oracle, ctx):
         assert (st[s] == rs.ravel()).mean() >= STATUS_AGREE
         both = (st[s] == 1) & (rs.ravel() == 1)
         assert both.mean() > 0.99 and np.abs(out[s][both] - ro[both]).max() <= POS_TOL
+
+
+@pytest.mark.parametrize("shape", [(22, 22), (22, 90), (44, 43), (88, 175), (176, 350)])
+def test_klt_levels_of_22_pixels(oracle, ctx, klt_kernel, shape):
+    """Image sizes whose last pyramid level is exactly 22 pixels wide or high, the smallest OpenCV's level rule
+    admits (every level larger than the 21-pixel window); keypoints up to and beyond the border."""
+    img0, img1, _ = synth.frame_pair(shape, seed=shape[0] + shape[1], max_shift=2.0)
+    pts = synth.uniform_keypoints(shape, 400, seed=1, margin=-8)
+    agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=8)
+    assert agree >= STATUS_AGREE and d <= POS_TOL and n_both > 50

@@ -754,8 +754,9 @@ static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
         a.lv[l].pstride = prev->img_stride[l];
         a.lv[l].npitch = next->pitch[l];
         a.lv[l].nstride = next->img_stride[l];
-        // the reflect helper is valid for one fold only
-        VO_REQUIRE(prev->w[l] > KLT_WIN + 1 && prev->h[l] > KLT_WIN + 1, "vo_klt_track: level %d (%dx%d) too small", l, prev->w[l], prev->h[l]);
+        // OpenCV's level rule (every level larger than the window).  It is also what the reflect helper needs: a
+        // valid window reads pixels -21 .. n + 20, one fold on either side once n >= 22.
+        VO_REQUIRE(prev->w[l] > KLT_WIN && prev->h[l] > KLT_WIN, "vo_klt_track: level %d (%dx%d) too small", l, prev->w[l], prev->h[l]);
     }
     return VO_OK;
 }
