@@ -150,6 +150,18 @@ def main():
                 "ms": ms_f, "frames_per_s": B / (ms_f * 1e-3), "algorithmic_bytes_per_frame": nbytes,
                 "roofline": {"bound": "hbm", "achieved": nbytes * B / (ms_f * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
                              "frac": nbytes * B / (ms_f * 1e-3) / 1e9 / HBM}})
+    # ---- the reference's Harris tail: dilate + threshold mask, cornerSubPix ------------
+    ms_m = timed(ctx, lambda: hip.harris_mask(ctx, timg, 0.1, 0.01, hip.HARRIS))
+    out.append({"op": "harris_mask (response + 3x3 dilation + threshold)", "workload": f"{B} frames 1241x376", "ms": ms_m,
+                "frames_per_s": B / (ms_m * 1e-3), "algorithmic_bytes_per_frame": 2 * h * w,
+                "roofline": {"bound": "hbm", "achieved": 2 * h * w * B / (ms_m * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
+                             "frac": 2 * h * w * B / (ms_m * 1e-3) / 1e9 / HBM}})
+    cpts = torch.from_numpy(synth.uniform_keypoints((h, w), 2000, seed=4, margin=12)).to(dev)
+    ms_s = timed(ctx, lambda: hip.corner_subpix(ctx, timg[0], cpts, (5, 5), 50, 0.001))
+    cms = cpu_time(lambda: oracle.corner_subpix(img, cpts.cpu().numpy(), (5, 5), 50, 0.001))
+    out.append({"op": "corner_subpix", "workload": "2000 corners on one 1241x376 frame, 11x11 window, <= 50 rounds, eps 1e-3 "
+                "(one corner per wavefront)", "ms": ms_s, "corners_per_s": 2000 / (ms_s * 1e-3), "cpu_oracle_ms": cms, "cpu_cores": 1})
+
     # ---- descriptor matching: two nearest neighbours + ratio test ------------------
     MFMA_BF16 = 2500.0          # dense bf16 peak, TFLOP/s
     for n1, n2, kind in [(3000, 3000, "bytes"), (3000, 3000, "float"), (16384, 16384, "bytes"), (16384, 16384, "float")]:
