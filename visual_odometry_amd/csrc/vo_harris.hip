@@ -705,18 +705,37 @@ extern "C" int vo_detect_corners(vo_ctx *ctx, const uint8_t *img, int batch, int
 __global__ __launch_bounds__(256) void harris_mask_kernel(const float *__restrict__ R, int w, int h, double rel_thresh,
                                                           const uint32_t *__restrict__ maxkey, uint8_t *__restrict__ mask)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= w || y >= h) return;
+    // a lane owns four neighbouring pixels of one row: six reads per row of the 3x3 neighbourhood, 18 per four pixels
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x0 >= w || y >= h) return;
     const float thr = (float)(rel_thresh * (double)key_value(maxkey[b * MAXKEY_STRIDE]));
     const float *img = R + (size_t)b * w * h;
-    float m = img[(size_t)y * w + x];
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-            m = fmaxf(m, img[(size_t)yy * w + xx]);
+    const float ninf = __uint_as_float(0xff800000u);
+    float m[4] = {ninf, ninf, ninf, ninf};
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        const float *row = img + (size_t)yy * w;
+        float v[6];
+        if (x0 >= 1 && x0 + 5 <= w) {
+            __builtin_memcpy(v, row + x0 - 1, 24);        // interior: the six values in one unaligned read
+        } else {
+            for (int c = 0; c < 6; ++c) {
+                const int xx = x0 - 1 + c;
+                v[c] = (xx >= 0 && xx < w) ? row[xx] : ninf;
+            }
         }
-    mask[(size_t)b * w * h + (size_t)y * w + x] = m > thr ? 255 : 0;
+        for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], fmaxf(v[c], fmaxf(v[c + 1], v[c + 2])));
+    }
+    uint8_t *out = mask + (size_t)b * w * h + (size_t)y * w + x0;
+    if (x0 + 4 <= w) {
+        const uint32_t packed = (m[0] > thr ? 0xffu : 0u) | (m[1] > thr ? 0xff00u : 0u) | (m[2] > thr ? 0xff0000u : 0u) |
+                                (m[3] > thr ? 0xff000000u : 0u);
+        __builtin_memcpy(out, &packed, 4);                // rows are not dword-aligned in general: unaligned store
+    } else {
+        for (int c = 0; c < 4; ++c)
+            if (x0 + c < w) out[c] = m[c] > thr ? 255 : 0;
+    }
 }
 
 extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
@@ -756,7 +775,7 @@ extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int he
     VO_REQUIRE(grid.y <= 65535u, "vo_harris_mask: image too tall");
     hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
                        d_max);
-    dim3 mgrid((width + 63) / 64, (height + 3) / 4, batch);
+    dim3 mgrid((width + 255) / 256, (height + 3) / 4, batch);
     VO_REQUIRE(mgrid.y <= 65535u, "vo_harris_mask: image too tall");
     hipLaunchKernelGGL(harris_mask_kernel, mgrid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh, d_max, d_mask);
     VO_HIP_CHECK(hipGetLastError());
