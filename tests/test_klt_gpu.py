@@ -237,3 +237,23 @@ def test_klt_levels_of_22_pixels(oracle, ctx, klt_kernel, shape):
     pts = synth.uniform_keypoints(shape, 400, seed=1, margin=-8)
     agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=8)
     assert agree >= STATUS_AGREE and d <= POS_TOL and n_both > 50
+
+
+def test_klt_initial_estimates(oracle, ctx, klt_kernel):
+    """init_pts (the search starts there instead of at prev_pts, OpenCV's OPTFLOW_USE_INITIAL_FLOW): a 40-pixel
+    shift that the plain call cannot follow is tracked from rough initial estimates; GPU and oracle agree."""
+    from visual_odometry_amd import hip
+    h, w = 240, 320
+    img0, img1, A = synth.frame_pair((h, w), seed=77, max_shift=40.0, margin=64)
+    pts = synth.uniform_keypoints((h, w), 500, seed=5, margin=45)
+    truth = (pts @ A[:, :2].T + A[:, 2]).astype(np.float32)
+    init = (truth + np.random.default_rng(3).uniform(-3, 3, truth.shape)).astype(np.float32)
+    p0 = hip.Pyramid(ctx, 1, h, w, 3).build(img0)
+    p1 = hip.Pyramid(ctx, 1, h, w, 3).build(img1)
+    out, st, _ = hip.klt_track(ctx, p0, p1, pts, init_pts=init)
+    ro, rs, _ = oracle.klt(img0, img1, pts, max_level=3, init_pts=init)
+    assert (st[0] == rs.ravel()).mean() >= STATUS_AGREE
+    both = (st[0] == 1) & (rs.ravel() == 1)
+    assert both.sum() > 300 and np.abs(out[0][both] - ro[both]).max() <= POS_TOL
+    inside = both & (truth[:, 0] > 12) & (truth[:, 0] < w - 13) & (truth[:, 1] > 12) & (truth[:, 1] < h - 13)
+    assert np.median(np.linalg.norm(out[0][inside] - truth[inside], axis=1)) < 0.1
