@@ -7,16 +7,28 @@ in HBM) gets its pyramid built and the stream's 2000 keypoints are tracked from
 the previous frame's pyramid (kept from the step before) into it.  Streams are
 independent, so N GPUs run N x streams-per-GPU streams with no per-frame
 communication (weak scaling); ranks only meet at the barriers around the timed
-region and in a final gather of per-stream tracked counts.
+region and in a final gather of every stream's tracked positions.
 
-Prints ONE JSON line on rank 0.  roofline.achieved prices the tracker kernel's own
-algorithmic bytes against its launch duration, taken with HIP events on the launch
-stream around every fourth tracker launch of the timed region (an event pair costs a
-few microseconds of idle queue, so not every step carries one).
+Launching: `python bench.py --gpus N` starts N rank processes by itself (the parent
+never touches a GPU); under `python -m torch.distributed.run` (WORLD_SIZE set) the
+process is one of the ranks.  Prints ONE JSON line on rank 0.
+
+A GPU's streams are dealt to `--groups` launch groups (default 2).  Each group owns a
+tracker HIP stream and a pyramid HIP stream and issues one tracker launch per step, so
+the launches of different groups overlap: one group's launch fills the drain of the
+other's.  roofline: `launch_ms` is the mean duration of one tracker launch, taken with
+HIP events on the launch's own stream around every fourth launch of every group in the
+timed region (an event pair costs a few microseconds of idle queue, so not every step
+carries one); `launches_in_flight` = (sum of all launch durations) / (timed wall time) is
+the measured overlap; `achieved` = tracker algorithmic bytes of one launch x
+launches_in_flight / launch_ms, i.e. the bytes per second the kernel's launches process
+while it runs on the device (`achieved_per_launch` leaves the overlap out).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -80,24 +92,82 @@ def make_streams(stream_ids, ring, base_seed=2021):
     return frames, pts
 
 
-def cpu_baseline(frames, pts, max_level=MAX_LEVEL, budget_s=12.0):
-    """Single-thread CPU oracle on the same workload (bounded sample)."""
+def host_cores():
+    """Worker threads for the all-cores CPU column: the process's CPU share, at most 16
+    (a one-GPU slice of a shared box shows every CPU of the machine in os.cpu_count())."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            n = min(n, int(v))
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(frames, pts, max_level=MAX_LEVEL, budget_s=10.0, cores=0):
+    """CPU oracle on the same workload (bounded sample): one thread, then `cores` threads
+    (the C oracle is called through ctypes, which releases the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     ring, n_streams = frames.shape[:2]
+
+    def pair(i):
+        s, r = i % n_streams, (i // n_streams) % ring
+        oracle.klt(frames[r, s], frames[(r + 1) % ring, s], pts[s], max_level=max_level)
+
     done, t0 = 0, time.perf_counter()
     while True:
-        s, r = done % n_streams, (done // n_streams) % ring
-        oracle.klt(frames[r, s], frames[(r + 1) % ring, s], pts[s], max_level=max_level)
+        pair(done)
         done += 1
         el = time.perf_counter() - t0
         if el >= budget_s and done >= 3:
             break
-    return {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frame pairs of the same streams ({N_KP} keypoints each, pyramids of both frames "
-                      f"rebuilt per pair as the reference's cv2 call does), {el:.1f} s"}
+    res = {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{done} frame pairs of the same streams ({N_KP} keypoints each, pyramids of both frames "
+                     f"rebuilt per pair as the reference's cv2 call does), {el:.1f} s"}
+    cores = cores or host_cores()
+    if cores > 1:
+        per = max(1, int(round(done / el * budget_s)))    # pairs one thread finishes in the budget
+        total = per * cores
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:
+            list(pool.map(pair, range(total)))
+        el = time.perf_counter() - t0
+        res["all_cores"] = {"value": total / el, "unit": "frames/s", "cores": cores, "kind": "port",
+                            "sample": f"{total} frame pairs over {cores} threads, {el:.1f} s"}
+    return res
 
 
-def main():
+def launch_ranks(n, argv):
+    """Parent of a self-launched multi-GPU run: start one fresh process per rank, wait, and pass
+    on the first failure.  This process never initialises a GPU and replaces no running program."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:           # a rank failed: the others would wait at a barrier for ever
+                    q.terminate()
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -108,29 +178,77 @@ def main():
     ap.add_argument("--total-streams", type=int, default=0,
                     help="strong scaling: this many streams in all, divided over the GPUs (must divide evenly); "
                          "default 0 = weak scaling with --streams-per-gpu streams on every GPU")
-    ap.add_argument("--ring", type=int, default=3)
+    ap.add_argument("--groups", type=int, default=2,
+                    help="launch groups per GPU: the GPU's streams are dealt to this many groups, each with its own "
+                         "tracker/pyramid HIP streams and one tracker launch per step (1 = one launch per step)")
+    ap.add_argument("--ring", type=int, default=3, help="distinct frames per stream, cycled through")
     ap.add_argument("--max-level", type=int, default=MAX_LEVEL,
                     help="requested last pyramid level (default 3 = the headline 4-level configuration; the reference "
                          "asks for 8, which the level-size rule clamps to 4 on 1241x376 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the all-cores CPU column (0 = the CPU share)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="build each frame's pyramid on the tracker's stream, right before it is tracked")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the multi-rank protocol without a GPU: rendezvous, sharding, barriers, MAX over "
+                         "ranks and the final gather run on CPU tensors (use --backend gloo); no kernel is launched")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal aid: every rank uses GPU 0 (one-GPU box); never used for reported numbers")
     ap.add_argument("--distinct", type=int, default=0,
                     help="development aid: synthesise only this many distinct streams and repeat them (0 = all distinct)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def dry_run(args, rank, world):
+    """The rank protocol of the benchmark on CPU tensors: what a stream 'tracked' is a function of its
+    global id, so rank 0 can check that the gather returned every stream's rows in global order."""
     import torch
     import torch.distributed as dist
-    from visual_odometry_amd import hip, streams
+    from visual_odometry_amd import streams
+    dev = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    S = args.total_streams // world if args.total_streams else args.streams_per_gpu
+    owned = streams.shard_streams(S * world, rank, world)
+    n_kp = 8
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    local = torch.stack([torch.full((n_kp, 2), float(streams.stream_seed(2021, s))) for s in owned])
+    if world > 1:
+        dist.barrier()
+    elapsed = streams.max_over_ranks(time.perf_counter() - t0 + 1e-3 * (rank + 1), dev, world)
+    tracks = streams.gather_per_stream(local, owned, S * world, world)
+    ok = bool((tracks[:, 0, 0] == torch.tensor([float(streams.stream_seed(2021, s)) for s in range(S * world)])).all())
+    if rank == 0:
+        print(json.dumps({"metric": "tracked frames/s (KITTI 1241x376, 2k kp)", "value": None, "unit": "frames/s",
+                          "dry_run": True, "n_gpus": world, "streams": S * world, "gather_ok": ok,
+                          "gathered_shape": list(tracks.shape), "max_elapsed_s": elapsed}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))     # before torch or HIP is touched in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
+
+    import torch
+    import torch.distributed as dist
+    from visual_odometry_amd import hip, streams
+
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -146,6 +264,7 @@ def main():
             raise SystemExit(f"--total-streams {args.total_streams} does not divide over {world} GPUs")
         args.streams_per_gpu = args.total_streams // world
     S, R = args.streams_per_gpu, args.ring
+    G = max(1, min(args.groups, S))
     owned = streams.shard_streams(S * world, rank, world)      # weak scaling: S streams per GPU
     if args.distinct and args.distinct < S:
         f0, p0 = make_streams(owned[:args.distinct], R)
@@ -156,47 +275,60 @@ def main():
         frames_h, pts_h = make_streams(owned, R)
     frames = torch.from_numpy(frames_h).to(dev)          # (R, S, H, W) resident in HBM
     pts = torch.from_numpy(pts_h).to(dev)
-    # Two HIP streams per GPU.  The tracker runs on a high-priority stream; the pyramid of the frame
-    # after next is built on a normal-priority one, so its workgroups are dispatched where the
-    # tracker leaves room -- in practice while the tracker's last workgroups drain.  Three pyramid
-    # slots: step k tracks slot k%3 -> (k+1)%3 while frame k+2 is built into slot (k+2)%3, which
-    # the tracker of step k-1 was the last to read.  Every step still builds one pyramid and
-    # tracks one frame per stream.
-    if args.no_pipeline:
-        s_klt = s_pyr = torch.cuda.current_stream(dev)
-    else:
-        s_klt = torch.cuda.Stream(device=dev, priority=-1)
-        s_pyr = torch.cuda.Stream(device=dev, priority=0)
-    with torch.cuda.stream(s_klt):
-        ctx = hip.Context.from_torch(local_rank)
-    with torch.cuda.stream(s_pyr):
-        ctx_pyr = hip.Context.from_torch(local_rank)
-    pyrs = [hip.Pyramid(ctx_pyr, S, H, W, args.max_level) for _ in range(3)]
-    eff_level = pyrs[0].max_level
-    out = (torch.empty_like(pts), torch.empty((S, N_KP), dtype=torch.uint8, device=dev),
-           torch.empty((S, N_KP), dtype=torch.float32, device=dev))
-    pyr_done = [torch.cuda.Event() for _ in range(3)]
-    klt_done = [torch.cuda.Event() for _ in range(3)]
+    out_pts = torch.empty_like(pts)
+    out_status = torch.empty((S, N_KP), dtype=torch.uint8, device=dev)
+    out_err = torch.empty((S, N_KP), dtype=torch.float32, device=dev)
+
+    # Launch groups.  A group owns local streams lo..hi, two HIP streams and three pyramid slots.  Its
+    # tracker runs on a high-priority HIP stream; the pyramid of the frame after next is built on a
+    # normal-priority one, so its workgroups are dispatched where the trackers leave room.  Step k of a
+    # group tracks slot k%3 -> (k+1)%3 while frame k+2 is built into slot (k+2)%3, which the tracker of
+    # step k-1 was the last to read.  Every step still builds one pyramid and tracks one frame per stream.
+    bounds = [S * g // G for g in range(G + 1)]
+    groups = []
+    for g in range(G):
+        lo, hi = bounds[g], bounds[g + 1]
+        if args.no_pipeline:
+            s_klt = s_pyr = torch.cuda.Stream(device=dev, priority=-1) if G > 1 else torch.cuda.current_stream(dev)
+        else:
+            s_klt = torch.cuda.Stream(device=dev, priority=-1)
+            s_pyr = torch.cuda.Stream(device=dev, priority=0)
+        with torch.cuda.stream(s_klt):
+            ctx = hip.Context.from_torch(local_rank)
+        with torch.cuda.stream(s_pyr):
+            ctx_pyr = hip.Context.from_torch(local_rank)
+        groups.append({
+            "n": hi - lo, "s_klt": s_klt, "s_pyr": s_pyr, "ctx": ctx,
+            "frames": [frames[r, lo:hi] for r in range(R)], "pts": pts[lo:hi],
+            "out": (out_pts[lo:hi], out_status[lo:hi], out_err[lo:hi]),
+            "pyrs": [hip.Pyramid(ctx_pyr, hi - lo, H, W, args.max_level) for _ in range(3)],
+            "pyr_done": [torch.cuda.Event() for _ in range(3)], "klt_done": [torch.cuda.Event() for _ in range(3)],
+            "evs": []})
+    eff_level = groups[0]["pyrs"][0].max_level
     torch.cuda.synchronize()
 
+    for q in groups:
+        for f in (0, 1):
+            q["pyrs"][f].build(q["frames"][f % R])
+            q["pyr_done"][f].record(q["s_pyr"])
+        q["klt_done"][2].record(q["s_klt"])      # slot 2 is free from the start
     state = {"t": 0}
-    for f in (0, 1):
-        pyrs[f].build(frames[f % R])
-        pyr_done[f].record(s_pyr)
-    klt_done[2].record(s_klt)      # slot 2 is free from the start
 
-    def step(ev=None):
+    def step(timed=False):
         k = state["t"]
-        s_pyr.wait_event(klt_done[(k + 2) % 3])          # = step k-1, the last reader of the slot
-        pyrs[(k + 2) % 3].build(frames[(k + 2) % R])
-        pyr_done[(k + 2) % 3].record(s_pyr)
-        s_klt.wait_event(pyr_done[(k + 1) % 3])
-        if ev:
-            ev[0].record(s_klt)
-        hip.klt_track(ctx, pyrs[k % 3], pyrs[(k + 1) % 3], pts, out=out)
-        if ev:
-            ev[1].record(s_klt)
-        klt_done[k % 3].record(s_klt)
+        for q in groups:
+            q["s_pyr"].wait_event(q["klt_done"][(k + 2) % 3])          # = step k-1, the last reader of the slot
+            q["pyrs"][(k + 2) % 3].build(q["frames"][(k + 2) % R])
+            q["pyr_done"][(k + 2) % 3].record(q["s_pyr"])
+            q["s_klt"].wait_event(q["pyr_done"][(k + 1) % 3])
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                q["evs"].append(ev)
+                ev[0].record(q["s_klt"])
+            hip.klt_track(q["ctx"], q["pyrs"][k % 3], q["pyrs"][(k + 1) % 3], q["pts"], out=q["out"])
+            if timed:
+                ev[1].record(q["s_klt"])
+            q["klt_done"][k % 3].record(q["s_klt"])
         state["t"] = k + 1
 
     def fence():
@@ -215,56 +347,74 @@ def main():
     for _ in range(args.warmup):
         step()
     EV_EVERY = 4
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(evs[k // EV_EVERY] if k % EV_EVERY == 0 else None)
+        step(timed=(k % EV_EVERY == 0))
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     elapsed = streams.max_over_ranks(elapsed, dev, world)
 
-    klt_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    tracked = out[1].sum(dim=1).to(torch.int32)           # per-stream tracked keypoints of the last step
-    tracked = streams.gather_per_stream(tracked, owned, S * world, world)   # the only data exchange: a final gather
-    tracked_frac = float(tracked.float().mean().item()) / N_KP
+    # per-launch durations, per group size (groups may differ by one stream)
+    launch_ms = float(np.mean([a.elapsed_time(b) for q in groups for a, b in q["evs"]]))
+    busy_ms = sum(float(np.mean([a.elapsed_time(b) for a, b in q["evs"]])) * args.steps for q in groups)
+    in_flight = busy_ms / (elapsed_local * 1e3)
+    # The only data exchange: every stream's tracked positions and flags of the last step, gathered to
+    # global stream order (S*world x 2000 x 2 float32 -- 16 KB per stream), outside the timed region.
+    tracks = streams.gather_per_stream(out_pts, owned, S * world, world)
+    status = streams.gather_per_stream(out_status, owned, S * world, world)
+    tracked_frac = float(status.float().mean().item())
 
     if rank == 0:
         frames_total = S * world * args.steps
         fps = frames_total / elapsed
         path_bytes, klt_bytes = algorithmic_bytes(eff_level, N_KP)
-        achieved = klt_bytes * S / (klt_ms * 1e-3) / 1e9
-        traffic = None
+        per_launch = klt_bytes * (S / G) / (launch_ms * 1e-3) / 1e9
+        achieved = per_launch * in_flight
+        roof = {"bound": "hbm", "kernel": "klt_track3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launch_ms": launch_ms, "frames_per_launch": S / G, "launches_in_flight": in_flight,
+                "achieved_per_launch": per_launch,
+                "bytes_per_frame_kernel": klt_bytes, "bytes_per_frame_path": path_bytes,
+                "timed_launches": sum(len(q["evs"]) for q in groups), "path_achieved": path_bytes * fps / world / 1e9}
+        # Counter-derived figures of the same build and workload (rocprofv3 --pmc passes, committed):
+        # HBM bytes per launch, VALU issue share, LDS bank-conflict share.
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                if rec.get("streams_per_gpu") == S and rec.get("kernel") == "klt_track3_kernel":
-                    traffic = rec.get("hbm_bytes_per_launch")
+                if rec.get("kernel") == roof["kernel"] and rec.get("frames_per_launch") == S / G:
+                    roof["traffic"] = rec.get("hbm_bytes_per_launch")
+                    for key in ("valu_issue", "lds_conflict_frac", "counters_from"):
+                        if key in rec:
+                            roof[key] = rec[key]
             except Exception:
-                traffic = None
+                pass
         res = {
             "metric": "tracked frames/s (KITTI 1241x376, 2k kp)", "value": fps, "unit": "frames/s",
             "keypoints_per_s": fps * N_KP, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "u8 images, int32 fixed-point bilinear, f32 normal equations",
             "data": "synthetic",
             "config": {"workload": f"KITTI-shaped 1241x376 u8 frames, 2000 keypoints/frame, {eff_level + 1}-level pyramid "
                                    f"(maxLevel={eff_level}), win 21, 10 iters, eps 1e-3, minEig 1e-2",
-                       "streams_per_gpu": S, "frames_per_launch": S, "ring_frames": R, "settle_ms": args.settle_ms,
-                       "schedule": "one stream" if args.no_pipeline else "pyramid of frame k+2 on a second HIP stream during tracker k",
+                       "streams_per_gpu": S, "launch_groups": G, "frames_per_launch": S / G, "ring_frames": R,
+                       "settle_ms": args.settle_ms,
+                       "schedule": "pyramid right before its tracker, one HIP stream per group" if args.no_pipeline
+                                   else "per group: pyramid of frame k+2 on a second HIP stream during tracker k",
                        "distinct_streams": (args.distinct if args.distinct and args.distinct < S else S) * world,
-                       "tracked_fraction": tracked_frac, "parallelism": f"stream-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "klt_track3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": klt_ms, "bytes_per_frame_kernel": klt_bytes, "bytes_per_frame_path": path_bytes,
-                         "timed_launches": len(evs), "path_achieved": path_bytes * fps / world / 1e9},
+                       "tracked_fraction": tracked_frac,
+                       "final_gather": {"tracks_shape": list(tracks.shape), "bytes": tracks.numel() * 4 + status.numel()},
+                       "parallelism": f"stream-parallel x{world}"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames_h, pts_h, max_level=eff_level)
+            res["cpu_baseline"] = cpu_baseline(frames_h, pts_h, max_level=eff_level, cores=args.cpu_cores)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -114,3 +114,17 @@ def linear_triangulation(pts1, pts2, M1, M2):
         _, _, VT = np.linalg.svd(A, full_matrices=False)
         P[i] = VT[-1]
     return (P.T / P[:, 3]).T
+
+
+def cheirality_votes(pts1, pts2, M1, M2, T_hat):
+    """The four-way vote of BootstrapInitializer._transform_matrix (vo_pipeline/bootstrap.py:110-124) for H candidate
+    motions: triangulate under each, count points with positive depth in camera 1 plus those with positive depth in
+    camera 2 (T_hat @ P in float64 on the float32 points, as numpy promotes it).  -> (clouds (H,n,4) f32, votes (H,)).
+    The triangulation under it is pinned by tests/golden/two_view.npz; the vote is the reference's two np.sum calls."""
+    clouds, votes = [], []
+    for Mh, Th in zip(np.asarray(M2), np.asarray(T_hat)):
+        P = linear_triangulation(pts1, pts2, M1, Mh)
+        Q = (Th @ P.T).T
+        clouds.append(P)
+        votes.append(int(np.sum(P[:, 2] > 0) + np.sum(Q[:, 2] > 0)))
+    return np.stack(clouds), np.asarray(votes, np.int64)

@@ -190,6 +190,47 @@ def test_two_view_geometry_matches_reference(ctx):
         hip.triangulate(ctx, d["p1"], d["p2"][:-1], d["M1"], d["M2"])
 
 
+def test_cheirality_vote_matches_oracle(ctx):
+    """All four motion hypotheses in one launch: clouds and in-front counts against the numpy restatement
+    (per-hypothesis reference triangulation + the reference's two np.sum counts), on the golden pair set and
+    on a noisy scene with outliers; host and device memory; the winner reproduces the reference's T and cloud."""
+    import torch
+    from oracle import solvers_np
+    from visual_odometry_amd import hip
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    d = np.load(os.path.join(GOLD, "two_view.npz"))
+    cases = [(d["K"], d["F"], d["p1"], d["p2"])]
+    sc = synth.two_view_scene(n=700, inlier_frac=0.8, noise=0.3, seed=17)
+    Kf = sc["K"].astype(np.float32)
+    Fm = sc["F"]
+    h1 = np.hstack([sc["m1"], np.ones((700, 1), np.float32)]).astype(np.float32)
+    h2 = np.hstack([sc["m2"], np.ones((700, 1), np.float32)]).astype(np.float32)
+    cases.append((Kf, Fm, h1, h2))
+    for K, F, p1, p2 in cases:
+        motions = BootstrapInitializer.motion_hypotheses(K.T @ F @ K)
+        assert motions.shape == (4, 3, 4)
+        for m in motions:
+            np.testing.assert_allclose(m[:, :3] @ m[:, :3].T, np.eye(3), atol=1e-9)
+            assert np.linalg.det(m[:, :3]) > 0
+        M1 = K @ np.eye(3, 4, dtype=np.float32)
+        M2 = np.stack([K @ m for m in motions])
+        ref_clouds, ref_votes = solvers_np.cheirality_votes(p1, p2, M1, M2, motions)
+        clouds, votes = hip.cheirality_vote(ctx, p1, p2, M1, M2, motions)
+        assert clouds.dtype == np.float32 and votes.dtype == np.int32
+        np.testing.assert_array_equal(votes, ref_votes)
+        np.testing.assert_allclose(clouds, ref_clouds, rtol=1e-5, atol=1e-4)
+        dc, dv = hip.cheirality_vote(ctx, torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda(), M1, M2, motions)
+        np.testing.assert_array_equal(dv.cpu().numpy(), votes)
+        np.testing.assert_array_equal(dc.cpu().numpy(), clouds)
+        # single-hypothesis call equals the plain triangulation
+        one, _ = hip.cheirality_vote(ctx, p1, p2, M1, M2[1:2], motions[1:2])
+        np.testing.assert_array_equal(one[0], hip.triangulate(ctx, p1, p2, M1, M2[1]))
+    e, v = hip.cheirality_vote(ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), M1, M2, motions)
+    assert e.shape == (4, 0, 4) and not v.any()
+    with pytest.raises(ValueError):
+        hip.cheirality_vote(ctx, p1, p2, M1, np.zeros((9, 3, 4)), np.zeros((9, 3, 4)))
+
+
 def test_klt_pyramid_reuse_is_transparent(ctx):
     """reuse_pyramids keeps the previous call's next-frame pyramid only for the identical array object;
     results equal the rebuild-everything path, and a different or modified-then-copied frame is rebuilt."""

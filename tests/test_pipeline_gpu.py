@@ -41,7 +41,7 @@ def _run(scene, frames, **kw):
 
 def test_loop_recovers_camera_path(ctx, sequence, parking_params):
     scene, frames = sequence
-    vo, states = _run(scene, frames)
+    vo, states = _run(scene, frames, rescale_bootstrap=True)      # one world scale, so the whole path is comparable
     assert len(states) == N_FRAMES and [s.idx for s in states] == list(range(N_FRAMES))
     # frames before the bootstrap carry the identity, the bootstrap frame is the first keyframe
     assert all(np.array_equal(s.pose, np.eye(4)) for s in states[:vo.frames_to_skip])
@@ -65,10 +65,11 @@ def test_loop_recovers_camera_path(ctx, sequence, parking_params):
 
 
 def test_loop_reference_scale_behaviour_runs(ctx, sequence, parking_params):
-    """rescale_bootstrap=False is the reference's active code: every re-bootstrap restarts the
+    """The default (rescale_bootstrap=False) is the reference's active code: every re-bootstrap restarts the
     scale at a unit baseline, so only the protocol is checked, not the metric path."""
     scene, frames = sequence
-    vo, states = _run(scene, frames, rescale_bootstrap=False)
+    vo, states = _run(scene, frames)
+    assert vo.rescale_bootstrap is False
     assert len(states) == N_FRAMES and len(vo.keyframes) >= 2
     for k in vo.keyframes[-1:]:       # no later window touched the poses around the last keyframe
         base = vo.frame_queue.get(N_FRAMES - 1 - (k.idx - 3)).pose

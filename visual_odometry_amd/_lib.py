@@ -64,6 +64,8 @@ SIGNATURES = {
                                             ctypes.c_int]),
     "vo_triangulate": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int, c_vp,
                                       ctypes.c_int]),
+    "vo_cheirality_vote": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, c_vp, c_vp, ctypes.c_int]),
     "vo_ba_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_f64p, ctypes.c_int,
                                     ctypes.c_int, ctypes.POINTER(c_vp)]),
     "vo_ba_destroy": (None, [c_vp]),

@@ -214,6 +214,10 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
     VO_REQUIRE(row_stride >= pyr->w[0], "vo_pyr_build: row_stride %lld < width %d", (long long)row_stride, pyr->w[0]);
     VO_REQUIRE(pyr->batch == 1 || img_stride >= row_stride * pyr->h[0], "vo_pyr_build: img_stride %lld too small", (long long)img_stride);
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_pyr_build: bad mem flag %d", mem);
+    // the tracker forms row offsets with a 24-bit multiply and 32-bit sums
+    VO_REQUIRE(row_stride < (1 << 24) && (int64_t)pyr->h[0] * row_stride < (1ll << 32),
+               "vo_pyr_build: row_stride %lld with %d rows exceeds the tracker's addressing (row_stride < 16 MiB, image < 4 GiB)",
+               (long long)row_stride, pyr->h[0]);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     if (mem == VO_MEM_HOST) {
         // tight library-owned copy of level 0 (+ slack for 4-byte row reads)

@@ -161,6 +161,19 @@ class Pyramid:
             pass
 
 
+def _device_points(t, batch: int, what: str):
+    """A (batch, n, 2) float32 contiguous GPU view of keypoints, or ValueError: the library reads raw pointers."""
+    import torch
+    if not (_is_torch(t) and t.is_cuda and t.dtype == torch.float32):
+        raise ValueError(f"{what} must be a float32 GPU tensor")
+    if t.numel() % (2 * batch):
+        raise ValueError(f"{what}: {tuple(t.shape)} does not reshape to ({batch}, n, 2)")
+    p = t.reshape(batch, -1, 2)
+    if not p.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    return p
+
+
 def klt_track(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, max_iters: int = 10, eps: float = 0.001,
               min_eig: float = 1e-2, init_pts=None, out=None):
     """Batched pyramidal LK.  pts: (B,N,2) or (N,2) float32.
@@ -171,19 +184,28 @@ def klt_track(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, max_iters: int = 1
     prm = KltParams(int(max_iters), float(eps), float(min_eig))
     if _is_torch(pts):
         import torch
-        p = pts.reshape(prev.batch, -1, 2)
-        assert p.dtype == torch.float32 and p.is_cuda and p.is_contiguous()
+        p = _device_points(pts, prev.batch, "klt_track: pts")
         n = p.shape[1]
+        if init_pts is not None:
+            init_pts = _device_points(init_pts, prev.batch, "klt_track: init_pts")
+            if init_pts.shape != p.shape:
+                raise ValueError(f"klt_track: init_pts {tuple(init_pts.shape)} vs pts {tuple(p.shape)}")
         if out is None:
             out = (torch.empty_like(p), torch.empty((prev.batch, n), dtype=torch.uint8, device=p.device),
                    torch.empty((prev.batch, n), dtype=torch.float32, device=p.device))
         o, s, e = out
+        for t, dt, shape, what in ((o, torch.float32, (prev.batch, n, 2), "next_pts"), (s, torch.uint8, (prev.batch, n), "status"),
+                                   (e, torch.float32, (prev.batch, n), "err")):
+            if not (_is_torch(t) and t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()):
+                raise ValueError(f"klt_track: out {what} must be a contiguous {dt} GPU tensor of shape {shape}")
         check(ctx.lib.vo_klt_track(ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(init_pts), n,
                                    ctypes.byref(prm), _ptr(o), _ptr(s), _ptr(e), VO_MEM_DEVICE), "vo_klt_track")
         return o, s, e
     p = np.ascontiguousarray(pts, dtype=np.float32).reshape(prev.batch, -1, 2)
     n = p.shape[1]
     ip = None if init_pts is None else np.ascontiguousarray(init_pts, dtype=np.float32).reshape(prev.batch, -1, 2)
+    if ip is not None and ip.shape != p.shape:
+        raise ValueError(f"klt_track: init_pts {ip.shape} vs pts {p.shape}")
     o = np.zeros_like(p)
     s = np.zeros((prev.batch, n), np.uint8)
     e = np.zeros((prev.batch, n), np.float32)
@@ -198,7 +220,7 @@ def klt_track_fb(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, lam: float, max
     prm = KltParams(int(max_iters), float(eps), float(min_eig))
     if _is_torch(pts):
         import torch
-        p = pts.reshape(prev.batch, -1, 2)
+        p = _device_points(pts, prev.batch, "klt_track_fb: pts")
         n = p.shape[1]
         o = torch.empty_like(p)
         m = torch.empty((prev.batch, n), dtype=torch.uint8, device=p.device)
@@ -462,6 +484,40 @@ def triangulate(ctx: Context, pts1, pts2, M1, M2):
     check(ctx.lib.vo_triangulate(ctx.handle, _ptr(pts1), _ptr(pts2), int(pts1.shape[0]), A.ctypes.data_as(_lib.c_f64p),
                                  B.ctypes.data_as(_lib.c_f64p), int(f1), int(f2), _ptr(out), mem), "vo_triangulate")
     return out
+
+
+def cheirality_vote(ctx: Context, pts1, pts2, M1, M2, T_hat):
+    """Triangulate every pair under each of H candidate motions and count the points in front of both
+    cameras, in one launch.  M1 (3,4); M2 (H,3,4) projection matrices; T_hat (H,3,4) motions [R|t].
+    -> (clouds (H,n,4) float32, in_front (H,) int32); numpy in -> numpy out with one synchronisation."""
+    f1 = getattr(M1, "dtype", None) == np.float32
+    f2 = getattr(M2, "dtype", None) == np.float32
+    A = np.ascontiguousarray(M1, np.float64).reshape(3, 4)
+    B = np.ascontiguousarray(M2, np.float64).reshape(-1, 3, 4)
+    T = np.ascontiguousarray(T_hat, np.float64).reshape(-1, 3, 4)
+    H = B.shape[0]
+    if T.shape[0] != H:
+        raise ValueError("cheirality_vote: M2 and T_hat differ in length")
+    if _is_torch(pts1):
+        import torch
+        pts1 = pts1.reshape(-1, 3).contiguous(); pts2 = pts2.reshape(-1, 3).contiguous()
+        if pts1.dtype != torch.float32 or pts2.dtype != torch.float32:
+            raise ValueError("cheirality_vote: device points must be float32")
+        clouds = torch.empty((H, pts1.shape[0], 4), dtype=torch.float32, device=pts1.device)
+        votes = torch.empty(H, dtype=torch.int32, device=pts1.device)
+        mem = VO_MEM_DEVICE
+    else:
+        pts1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 3)
+        pts2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 3)
+        clouds = np.zeros((H, pts1.shape[0], 4), np.float32)
+        votes = np.zeros(H, np.int32)
+        mem = VO_MEM_HOST
+    if pts2.shape[0] != pts1.shape[0]:
+        raise ValueError("cheirality_vote: point sets differ in length")
+    check(ctx.lib.vo_cheirality_vote(ctx.handle, _ptr(pts1), _ptr(pts2), int(pts1.shape[0]), A.ctypes.data_as(_lib.c_f64p),
+                                     B.ctypes.data_as(_lib.c_f64p), T.ctypes.data_as(_lib.c_f64p), int(H), int(f1), int(f2),
+                                     _ptr(clouds), _ptr(votes), mem), "vo_cheirality_vote")
+    return clouds, votes
 
 
 def harris_mask(ctx: Context, imgs, k: float = 0.1, rel_thresh: float = 0.01, mode: int = HARRIS):

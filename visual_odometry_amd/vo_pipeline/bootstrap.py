@@ -7,8 +7,9 @@ kernel (descriptors pts_des1/pts_des2 are then zero-filled (n,128) arrays); a ca
 that has keypoints and descriptors of both images passes them as `features` and gets
 the reference's route, two-nearest-neighbour matching with the ratio test
 (bootstrap.py:188-211), on the GPU.  The fundamental matrix comes from
-ransac.find_fundamental_mat (GPU-scored RANSAC) instead of cv2.findFundamentalMat.  The two-view geometry after F follows the
-reference step by step (pinned by tests/golden/two_view.npz).
+ransac.find_fundamental_mat (GPU-scored RANSAC) instead of cv2.findFundamentalMat.  The two-view geometry after F (motion hypotheses, cheirality vote, feasibility mask) is this
+build's own formulation of bootstrap.py:76-138 with the vote on the GPU; its outputs are pinned by
+tests/golden/two_view.npz (outputs of the reference functions).
 """
 import logging
 from typing import Tuple
@@ -95,44 +96,51 @@ class BootstrapInitializer:
         keep = mask.ravel() == 1
         return F, pts0[keep], pts1[keep], des0[keep], des1[keep]
 
+    @staticmethod
+    def motion_hypotheses(E: np.ndarray) -> np.ndarray:
+        """The four motions [R|t] (4,3,4) float64 an essential matrix admits, in the order the vote
+        visits them (bootstrap.py:89-111): two rotations from the SVD of E, each paired with the
+        unit left-null direction of E taken negative first."""
+        U, _, Vt = np.linalg.svd(E)
+        quarter_turn = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+        baseline = U[:, 2].copy()
+        if np.any(baseline != 0):
+            baseline /= np.linalg.norm(baseline)
+        motions = np.empty((4, 3, 4))
+        for r, twist in enumerate((quarter_turn, quarter_turn.T)):
+            R = U @ twist @ Vt
+            if np.linalg.det(R) < 0:         # a reflection: E is defined up to sign
+                R = -R
+            for s, sign in enumerate((-1.0, 1.0)):
+                motions[2 * r + s, :, :3] = R
+                motions[2 * r + s, :, 3] = sign * baseline
+        return motions
+
     def _transform_matrix(self, F: np.ndarray, pts1: np.ndarray, pts2: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """E = K^T F K -> (R, t) by the 4-way cheirality test on triangulated points.
-        Returns (T (4,4) float32, point cloud (n,4) in camera 1, feasibility mask)."""
-        E = self.K.T @ F @ self.K
-        Wm = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
-        U, _, VT = np.linalg.svd(E)
-        rotations = [U @ Wm @ VT, U @ Wm.T @ VT]
-        rotations = [-R if np.linalg.det(R) < 0 else R for R in rotations]
-        u = U[:, -1][np.newaxis].T
-        if not np.all(u == 0):
-            u = u / np.linalg.norm(u)
+        """Relative pose from F (bootstrap.py:76-138): E = K^T F K, its four motion hypotheses put to the
+        vote of points in front of both cameras -- all four triangulations and the four counts in one GPU
+        launch --, then the feasibility mask on the winner's cloud.
+        Returns (T (4,4) float32, point cloud (n,4) float32 in camera 1, mask (n,) bool)."""
+        motions = self.motion_hypotheses(self.K.T @ F @ self.K)
         M1 = self.K @ np.eye(3, 4, dtype=np.float32)
-        best = None
-        most = -np.inf
-        for R_hat in rotations:
-            for u_hat in (-u, u):
-                T_hat = np.hstack((R_hat, u_hat))
-                P_cam1 = self._linear_triangulation(pts1, pts2, M1, self.K @ T_hat)
-                P_cam2 = (T_hat @ P_cam1.T).T
-                in_front = np.sum(P_cam1[:, 2] > 0) + np.sum(P_cam2[:, 2] > 0)
-                if in_front > most:
-                    most = in_front
-                    best = (R_hat, u_hat, P_cam1, -R_hat.T @ u_hat)
-        R, t, point_cloud, cam2_W = best
+        M2 = np.stack([self.K @ m for m in motions])
+        clouds, votes = hip.cheirality_vote(_runtime.context(), pts1, pts2, M1, M2, motions)
+        won = int(np.argmax(votes))              # first of equal counts, like a strict '>' scan
+        point_cloud = clouds[won]
         T = np.eye(4, dtype=np.float32)
-        T[0:3, 0:3] = R
-        T[0:3, 3] = t.ravel()
-        min_real_z = min(0, cam2_W[2])
-        close_enough = np.linalg.norm(point_cloud[:, 0:3], axis=1) <= self.max_point_dist
-        in_front_cam = point_cloud[:, 2] > min_real_z
-        mask = close_enough & in_front_cam
-        logging.info(f"Rejected {np.sum(~mask)} points during 3D reconstruction.")
+        T[0:3, :] = motions[won]
+        # camera 2's centre in camera-1 coordinates; points may lie behind camera 1 only as far as it does
+        centre2_z = float(-(motions[won, :, :3].T @ motions[won, :, 3])[2])
+        depth_floor = min(0.0, centre2_z)
+        mask = (np.linalg.norm(point_cloud[:, 0:3], axis=1) <= self.max_point_dist) & (point_cloud[:, 2] > depth_floor)
+        logging.info("two-view reconstruction: %d of %d points rejected (too far or behind the cameras)",
+                     int(np.count_nonzero(~mask)), mask.size)
         return T, point_cloud, mask
 
     @staticmethod
     def _linear_triangulation(pts1: np.ndarray, pts2: np.ndarray, M1: np.ndarray, M2: np.ndarray) -> np.ndarray:
         """DLT triangulation of homogeneous pixel pairs (n,3) -> (n,4) float32 points with last
         column 1; one point per GPU lane instead of the reference's per-point SVD loop."""
-        assert pts1.shape == pts2.shape, "The number of matched points in both images has to be the same"
-        assert M1.shape == M2.shape == (3, 4), "Homogeneous projection matrices have be of shape (3,4)"
+        assert pts1.shape == pts2.shape, f"point sets differ: {pts1.shape} vs {pts2.shape}"
+        assert M1.shape == (3, 4) and M2.shape == (3, 4), "projection matrices must be (3,4)"
         return hip.triangulate(_runtime.context(), pts1, pts2, M1, M2)

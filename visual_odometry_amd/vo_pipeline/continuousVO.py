@@ -96,14 +96,14 @@ class ContinuousVO:
     corner detector + KLT (SIFT and descriptor matching are not part of this build).
 
     rescale_bootstrap: a re-bootstrap triangulates with a unit baseline (bootstrap.py:103-111).
-    With True (default) the new translation and landmarks are scaled so that the baseline equals the
-    one implied by `world_transform` -- the step the reference carries as commented-out code
-    (continuousVO.py:128-135) -- which keeps one world scale across keyframes; False reproduces
-    the reference's active code path."""
+    False (default) is the reference's active code path: every keyframe restarts the scale.  True is
+    an opt-in extension: the new translation and landmarks are scaled so that the baseline equals
+    the one implied by the tracked pose -- the step the reference carries as commented-out code
+    (continuousVO.py:128-135) -- which keeps one world scale across keyframes."""
 
     def __init__(self, dataset, descriptorType=ExtractorType.SIFT, matcherType=None, useKLT=True,
                  algo_method=AlgoMethod.P3P, max_point_distance: int = 100, frames_to_skip: int = 10,
-                 frame_queue_size: int = 1000, rescale_bootstrap: bool = True) -> None:
+                 frame_queue_size: int = 1000, rescale_bootstrap: bool = False) -> None:
         self.dataset = dataset
         self.descriptor = FeatureExtractor(descriptorType)
         self.matcher = matcherType
