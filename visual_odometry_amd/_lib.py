@@ -42,6 +42,8 @@ SIGNATURES = {
                                     c_vp, c_vp, c_vp, ctypes.c_int]),
     "vo_klt_track_fb": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.POINTER(KltParams),
                                        ctypes.c_float, c_vp, c_vp, ctypes.c_int]),
+    "vo_klt_track_fb_noalloc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.POINTER(KltParams),
+                                               ctypes.c_float, c_vp, c_vp]),
     "vo_score_fundamental": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_double,
                                             c_vp, c_vp, ctypes.c_int]),
     "vo_score_pnp": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, ctypes.c_int, ctypes.c_double,

@@ -44,6 +44,12 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
         vo_set_error("vo_ctx_create: device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
         return VO_ESTATE;
     }
+    {
+        static std::mutex setup_mu;
+        std::lock_guard<std::mutex> lk(setup_mu);
+        int rc = vo_klt_noalloc_setup(device);   // once per device, with that device current
+        if (rc) return rc;
+    }
     vo_ctx *c = new (std::nothrow) vo_ctx();
     if (!c) { vo_set_error("vo_ctx_create: out of host memory"); return VO_ENOMEM; }
     c->device = device;

@@ -43,6 +43,9 @@ struct vo_ctx {
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
 
+// Looks up the current device's copy of the fixed scratch array of vo_klt_track_fb_noalloc (vo_klt.hip).
+int vo_klt_noalloc_setup(int device);
+
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
 

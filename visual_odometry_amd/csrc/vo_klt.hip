@@ -907,3 +907,70 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
     }
     return VO_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Forward-backward tracking for callers that cannot allocate (HIP graph capture, tight
+// serving loops): the same three launches as vo_klt_track_fb, with the intermediate
+// results -- back-tracked points and the two status arrays, 10 bytes per keypoint -- in
+// a fixed device array instead of the context's growable staging buffers.
+// Every GPU holds its own copy of the array at its own address; the address is looked up
+// once per device (vo_klt_noalloc_setup, called by vo_ctx_create with that device
+// current) and only that pointer is ever handed to kernels.  Calls on one GPU share the
+// array: calls that overlap on one GPU (two contexts, two streams) race.  Nothing in it
+// has to start at zero -- each call's kernels write every entry they later read.
+// ---------------------------------------------------------------------------
+#define FB_MAX_KP VO_KLT_FB_NOALLOC_MAX_KEYPOINTS
+#define FB_OFF_BACK 0
+#define FB_OFF_SF ((size_t)FB_MAX_KP * 8)
+#define FB_OFF_SB (FB_OFF_SF + (size_t)FB_MAX_KP)
+#define FB_SCRATCH_BYTES (FB_OFF_SB + (size_t)FB_MAX_KP)
+static __device__ __align__(256) unsigned char scratch[FB_SCRATCH_BYTES];
+
+#define FB_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[FB_MAX_DEVICES];   // per device: address of that GPU's copy of `scratch`
+
+int vo_klt_noalloc_setup(int device)
+{
+    VO_REQUIRE(device >= 0 && device < FB_MAX_DEVICES, "vo_klt_noalloc_setup: device %d", device);
+    if (g_scratch_ptr[device]) return VO_OK;
+    void *p = nullptr;
+    VO_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));   // the current device's copy
+    VO_REQUIRE(p != nullptr, "vo_klt_noalloc_setup: no device address for the scratch array");
+    g_scratch_ptr[device] = (unsigned char *)p;
+    return VO_OK;
+}
+
+extern "C" int vo_klt_track_fb_noalloc(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, int n,
+                                       const vo_klt_params *params, float lambda, float *next_pts, uint8_t *mask)
+{
+    VO_REQUIRE(ctx && prev && next && params, "vo_klt_track_fb_noalloc: NULL argument");
+    VO_REQUIRE(n >= 0, "vo_klt_track_fb_noalloc: n=%d", n);
+    if (n == 0) return VO_OK;
+    VO_REQUIRE(prev_pts && next_pts && mask, "vo_klt_track_fb_noalloc: NULL point/mask buffer");
+    const int64_t cnt = (int64_t)n * prev->batch;
+    VO_REQUIRE(cnt <= FB_MAX_KP, "vo_klt_track_fb_noalloc: %lld keypoints (%d images x %d) exceed the fixed scratch of %d; "
+               "use vo_klt_track_fb", (long long)cnt, prev->batch, n, FB_MAX_KP);
+    VO_REQUIRE(ctx->device >= 0 && ctx->device < FB_MAX_DEVICES && g_scratch_ptr[ctx->device],
+               "vo_klt_track_fb_noalloc: scratch of device %d was not set up", ctx->device);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    unsigned char *base = g_scratch_ptr[ctx->device];
+    float *d_back = (float *)(base + FB_OFF_BACK);
+    uint8_t *d_sf = base + FB_OFF_SF, *d_sb = base + FB_OFF_SB;
+    int rc;
+    KltArgs f = {};
+    if ((rc = fill_levels(f, prev, next))) return rc;
+    set_params(f, params);
+    f.n = n;
+    f.prev_pts = prev_pts; f.next_pts = next_pts; f.status = d_sf;
+    if ((rc = launch_klt(ctx, f))) return rc;
+    KltArgs g = {};
+    if ((rc = fill_levels(g, next, prev))) return rc;
+    set_params(g, params);
+    g.n = n;
+    g.prev_pts = next_pts; g.next_pts = d_back; g.status = d_sb;
+    if ((rc = launch_klt(ctx, g))) return rc;
+    hipLaunchKernelGGL(klt_fb_check_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev_pts,
+                       (const float *)d_back, (const uint8_t *)d_sf, (const uint8_t *)d_sb, lambda, next_pts, mask, cnt);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
