@@ -386,7 +386,7 @@ def main(argv=None):
                 rec = json.load(open(tf))
                 if rec.get("kernel") == roof["kernel"] and rec.get("frames_per_launch") == S / G:
                     roof["traffic"] = rec.get("hbm_bytes_per_launch")
-                    for key in ("valu_issue", "lds_conflict_frac", "counters_from"):
+                    for key in ("valu_issue", "lds_conflict_frac", "lds_busy_frac", "valu_insts_per_keypoint", "counters_from"):
                         if key in rec:
                             roof[key] = rec[key]
             except Exception:

@@ -2,7 +2,7 @@
 # PMC passes over bench.py (one counter set per run; kernel-trace only).
 # usage: tools/pmc_passes.sh <outdir> [bench args...]
 set -u
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # two SQ counter passes over a short bench run
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -449,7 +449,16 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
 // accumulates b1 and b2 exactly in int32.
 // ---------------------------------------------------------------------------
 #define K3_S 25                        // tile row stride (dwords)
-#define K3_REGION (JT_ROWS * K3_S)     // one keypoint's tile region (dwords)
+// One keypoint's tile region (dwords).  A dword read serves lanes 0-31 and 32-63 in one LDS cycle each when
+// the 32 lanes of a half hit 32 different banks (bank = dword address mod 32).  A half holds 21 lanes of one
+// keypoint (consecutive columns = consecutive banks) and 10-11 lanes of the middle keypoint: the region
+// stride is padded from 26 * 25 = 650 to 661 dwords (661 mod 32 = 21, 2 * 661 mod 32 = 10), so that at equal
+// tile offsets keypoint 1's columns 0-10 follow keypoint 0's 21 banks, and keypoint 2's columns 0-20 follow
+// keypoint 1's columns 11-20: no two lanes of a half share a bank.  (With 650 the middle keypoint's lanes
+// sat on banks of their neighbours in both halves and every tile read took two cycles per half.)
+#define K3_REGION 661
+static_assert(K3_REGION >= (KLT_WIN + 1 + 2 * KLT_M) * K3_S, "region holds a next-image tile");
+static_assert(K3_REGION % 32 == 21, "bank offset of the middle keypoint");
 #define K3_WAVES 4
 #define K3_KP_WAVE 3
 #define K3_KP_BLOCK (K3_WAVES * K3_KP_WAVE)
