@@ -320,6 +320,29 @@ int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int height, int w
 int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, float *corners,
                      int count, int win_w, int win_h, int max_iters, double eps, int mem);
 
+/* ---- connected components; the whole of FeatureExtractor.harris ------------------------------------
+ * vo_connected_components replaces cv.connectedComponentsWithStats(dst)
+ * (vo_pipeline/featureExtraction.py:45) on one uint8 mask (nonzero = foreground): 8-connectivity,
+ * label 0 = background.  order 0 numbers the components in raster order of their first pixel,
+ * order 1 in raster order of their first 2x2 block (the numbering of the block-based labeller of
+ * OpenCV >= 4.5.2).  labels (height, width) int32, tight, may be NULL; centroids (max_labels, 2)
+ * float64 (x, y) = coordinate sums / area (an empty background sits at (0, 0)); areas (max_labels)
+ * int32, may be NULL; all three follow `mem`.  *n_labels (host) = number of components + 1; rows
+ * beyond max_labels are not written (at most ceil(h/2)*ceil(w/2) + 1 labels exist).  Synchronises
+ * the stream (the count returns to the host).
+ *
+ * vo_harris_corners replaces the body of FeatureExtractor.harris (featureExtraction.py:37-51) in one
+ * call with one synchronisation: cv.cornerHarris(float32(img), 2, 3, k), 3x3 dilation, threshold at
+ * rel_thresh * max, connected components, float32 centroids (background first), cv.cornerSubPix with
+ * half-window (win_w, win_h), max_iters, eps.  corners (max_corners, 2) float32 (x, y) follows `mem`;
+ * *n_corners (host) = number of labels; rows beyond max_corners are dropped.
+ */
+int vo_connected_components(vo_ctx *ctx, const uint8_t *mask, int height, int width, int64_t row_stride, int order,
+                            int32_t *labels, double *centroids, int32_t *areas, int max_labels, int32_t *n_labels, int mem);
+int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, float k, double rel_thresh,
+                      int order, int win_w, int win_h, int max_iters, double eps, float *corners, int max_corners,
+                      int32_t *n_corners, int mem);
+
 /* ---- descriptor matching -----------------------------------------------------------------
  * vo_knn_match2 replaces matcher.knnMatch(des1, des2, k=2) inside
  * FeatureMatcher.match_descriptors (vo_pipeline/featureMatching.py:52-63) and the ratio test

@@ -34,6 +34,7 @@ def lib():
         _declare_harris(_lib)
         _declare_match(_lib)
         _declare_subpix(_lib)
+        _declare_cc(_lib)
     return _lib
 
 
@@ -88,6 +89,12 @@ def _declare_subpix(L):
     L.vo_or_corner_subpix.restype = None
     L.vo_or_corner_subpix.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _f32p, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_double]
+
+
+def _declare_cc(L):
+    L.vo_or_connected_components.restype = ctypes.c_int
+    L.vo_or_connected_components.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _i32p, _f64p, _i32p,
+                                             ctypes.c_int]
 
 
 def _declare_match(L):
@@ -264,3 +271,26 @@ def corner_subpix(img, corners, win=(5, 5), max_iters=50, eps=0.001):
     lib().vo_or_corner_subpix(_p(img, _u8p), h, w, w, _p(out, _f32p), out.shape[0], int(win[0]), int(win[1]), int(max_iters),
                               float(eps))
     return out
+
+
+def connected_components(mask, order=1):
+    """8-connected components of a mask (nonzero = foreground) with statistics, as
+    cv.connectedComponentsWithStats -> (n_labels, labels (H,W) int32, centroids (n,2) float64 (x, y), areas (n,) int32);
+    order 0 numbers components by first pixel, order 1 by first 2x2 block (see vo_oracle_cc.c)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    cap = ((h + 1) // 2) * ((w + 1) // 2) + 1
+    labels = np.zeros((h, w), np.int32)
+    cen = np.zeros((cap, 2), np.float64)
+    areas = np.zeros(cap, np.int32)
+    n = lib().vo_or_connected_components(_p(mask, _u8p), h, w, w, int(order), _p(labels, _i32p), _p(cen, _f64p),
+                                         _p(areas, _i32p), cap)
+    return n, labels, cen[:n].copy(), areas[:n].copy()
+
+
+def harris_corners(img, k=0.1, rel_thresh=0.01, order=1, win=(5, 5), max_iters=50, eps=0.001):
+    """FeatureExtractor.harris end to end (reference vo_pipeline/featureExtraction.py:37-51): mask, components,
+    float32 centroids (background first), sub-pixel refinement -> (M,2) float32."""
+    mask = harris_mask(img, k, rel_thresh, 0)
+    _, _, cen, _ = connected_components(mask, order)
+    return corner_subpix(img, np.float32(cen), win, max_iters, eps)

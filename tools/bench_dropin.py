@@ -21,6 +21,13 @@ def t(fn, reps=20, warm=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+def _tm(p1, p2, sc, synth):
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    b = object.__new__(BootstrapInitializer)
+    b.K, b.max_point_dist = synth.K_KITTI, 100
+    return b._transform_matrix(sc["F"], p1, p2)
+
+
 def main():
     from visual_odometry_amd import synth
     from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
@@ -56,8 +63,10 @@ def main():
         "TrackPoints.trackKLT ms (forward+backward)": t(lambda: tp.trackKLT(img0, img1, pts)),
         "PoseEstimation.PnP ms (2000 points, 100 RANSAC iterations + refit)": t(lambda: pe.PnP(sc["X"], sc["m2"]), reps=10),
         "findFundamentalMat ms (2000 points, 100 iterations)": t(lambda: BootstrapInitializer.findFundamentalMat(sc["m1"], sc["m2"], 0.1, 0.9999, 100), reps=10),
-        "FeatureExtractor.harris ms (1241x376: mask on the GPU, labelling on the host, cornerSubPix on the GPU)": t(lambda: FeatureExtractor.harris(img0), reps=10),
+        "FeatureExtractor.harris ms (1241x376: mask, connected components, centroids, cornerSubPix in one GPU call)": t(lambda: FeatureExtractor.harris(img0), reps=10),
         "FeatureExtractor.corners ms (top-2000)": t(lambda: FeatureExtractor.corners(img0, 2000)),
+        "BootstrapInitializer._transform_matrix ms (2000 pairs: E decomposition on the host, four triangulations + vote in one launch)":
+            t(lambda: _tm(p1, p2, sc, synth)),
         "BootstrapInitializer._linear_triangulation ms (2000 pairs)": t(lambda: BootstrapInitializer._linear_triangulation(p1, p2, M1, M2)),
         "FeatureMatcher.match_descriptors ms (3000 x 3000 descriptors, list of DMatch objects)": t(lambda: fm.match_descriptors(des0, des1)),
         "FeatureMatcher.match_arrays ms (3000 x 3000 descriptors, index/distance/mask arrays)": t(lambda: fm.match_arrays(des0, des1)),

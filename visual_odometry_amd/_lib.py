@@ -89,6 +89,11 @@ SIGNATURES = {
                                       ctypes.c_float, ctypes.c_int, ctypes.c_double, c_vp, ctypes.c_int]),
     "vo_corner_subpix": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "vo_connected_components": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_vp, c_vp,
+                                               c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
+    "vo_harris_corners": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp,
+                                         ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
     "vo_knn_match2": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp, c_vp,
                                      c_vp, ctypes.c_int]),
 }

@@ -738,6 +738,36 @@ __global__ __launch_bounds__(256) void harris_mask_kernel(const float *__restric
     }
 }
 
+// Response + dilation + threshold on device pointers (response map and per-image maxima in context slots 1 and 6).
+static int harris_mask_launch(vo_ctx *ctx, const uint8_t *d_img, int batch, int height, int width, int64_t pitch, int64_t istride,
+                              float k, int mode, double rel_thresh, uint8_t *d_mask)
+{
+    int rc;
+    void *p;
+    const size_t npix = (size_t)width * height;
+    if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc;     // library-owned response map
+    float *d_R = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
+    uint32_t *d_max = (uint32_t *)p;
+    VO_HIP_CHECK(hipMemsetAsync(d_max, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
+    dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);
+    VO_REQUIRE(grid.y <= 65535u, "vo_harris_mask: image too tall");
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
+                       d_max);
+    dim3 mgrid((width + 255) / 256, (height + 3) / 4, batch);
+    VO_REQUIRE(mgrid.y <= 65535u, "vo_harris_mask: image too tall");
+    hipLaunchKernelGGL(harris_mask_kernel, mgrid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh, d_max, d_mask);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_harris_mask_device(vo_ctx *ctx, const uint8_t *d_img, int height, int width, int64_t pitch, float k, int mode,
+                          double rel_thresh, uint8_t *d_mask)
+{
+    VO_REQUIRE((int64_t)height * width < (1ll << 31), "harris mask: image too large");
+    return harris_mask_launch(ctx, d_img, 1, height, width, pitch, pitch * height, k, mode, rel_thresh, d_mask);
+}
+
 extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int height, int width, int64_t row_stride,
                               int64_t img_stride, float k, int mode, double rel_thresh, uint8_t *mask, int mem)
 {
@@ -766,19 +796,7 @@ extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int he
         }
         pitch = width; istride = (int64_t)npix;
     }
-    if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc;     // library-owned response map
-    float *d_R = (float *)p;
-    if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
-    uint32_t *d_max = (uint32_t *)p;
-    VO_HIP_CHECK(hipMemsetAsync(d_max, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
-    dim3 grid((width + HR_TW - 1) / HR_TW, (height + HR_TH - 1) / HR_TH, batch);
-    VO_REQUIRE(grid.y <= 65535u, "vo_harris_mask: image too tall");
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, ctx->stream, d_img, width, height, pitch, istride, k, mode, d_R,
-                       d_max);
-    dim3 mgrid((width + 255) / 256, (height + 3) / 4, batch);
-    VO_REQUIRE(mgrid.y <= 65535u, "vo_harris_mask: image too tall");
-    hipLaunchKernelGGL(harris_mask_kernel, mgrid, dim3(256), 0, ctx->stream, d_R, width, height, rel_thresh, d_max, d_mask);
-    VO_HIP_CHECK(hipGetLastError());
+    if ((rc = harris_mask_launch(ctx, d_img, batch, height, width, pitch, istride, k, mode, rel_thresh, d_mask))) return rc;
     if (mem == VO_MEM_HOST) {
         VO_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npix * batch, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -21,11 +21,13 @@ struct SubpixWeights { float m[(2 * SP_MAX_WIN + 1) * (2 * SP_MAX_WIN + 1)]; };
 
 __global__ __launch_bounds__(64) void corner_subpix_kernel(const uint8_t *__restrict__ img, int h, int w, int64_t stride,
                                                           float *__restrict__ corners, int count, int win_w, int win_h,
-                                                          int max_iters, double eps2, SubpixWeights wt)
+                                                          int max_iters, double eps2, SubpixWeights wt,
+                                                          const int *__restrict__ last_dev)
 {
     __shared__ float patch[(2 * SP_MAX_WIN + 3) * (2 * SP_MAX_WIN + 3)];
     __shared__ double terms[(2 * SP_MAX_WIN + 1) * (2 * SP_MAX_WIN + 1) * 5];
     const int lane = threadIdx.x, p = blockIdx.x;
+    if (last_dev && p > *last_dev) return;      // count known on the device only: corners 0 .. *last_dev exist
     const int ww = 2 * win_w + 1, wh = 2 * win_h + 1, bw = ww + 2, bh = wh + 2;
     const float ctx = corners[2 * p], cty = corners[2 * p + 1];
     float cx = ctx, cy = cty;      // every lane carries the same estimate
@@ -82,6 +84,38 @@ __global__ __launch_bounds__(64) void corner_subpix_kernel(const uint8_t *__rest
     }
 }
 
+static void subpix_weights(SubpixWeights &wt, int win_w, int win_h)
+{
+    memset(&wt, 0, sizeof(wt));
+    const int ww = 2 * win_w + 1, wh = 2 * win_h + 1;
+    for (int i = 0; i < wh; ++i) {                      // the window weights, in float as OpenCV forms them
+        const float y = (float)(i - win_h) / win_h;
+        const float vy = expf(-y * y);
+        for (int j = 0; j < ww; ++j) {
+            const float x = (float)(j - win_w) / win_w;
+            wt.m[i * ww + j] = (float)(vy * expf(-x * x));
+        }
+    }
+}
+
+// Refinement of corners 0 .. *d_last (a count that only the device knows yet; at most max_count corners),
+// device pointers, asynchronous.
+int vo_corner_subpix_device(vo_ctx *ctx, const uint8_t *d_img, int height, int width, int64_t pitch, float *d_corners,
+                            int max_count, const int *d_last, int win_w, int win_h, int max_iters, double eps)
+{
+    VO_REQUIRE(win_w >= 1 && win_h >= 1 && win_w <= SP_MAX_WIN && win_h <= SP_MAX_WIN, "corner refinement: window half-size (%d,%d) out of [1,%d]",
+               win_w, win_h, SP_MAX_WIN);
+    if (max_count <= 0) return VO_OK;
+    SubpixWeights wt;
+    subpix_weights(wt, win_w, win_h);
+    max_iters = max_iters < 1 ? 1 : (max_iters > 100 ? 100 : max_iters);
+    eps = eps > 0 ? eps : 0;
+    hipLaunchKernelGGL(corner_subpix_kernel, dim3(max_count), dim3(64), 0, ctx->stream, d_img, height, width, pitch, d_corners,
+                       max_count, win_w, win_h, max_iters, eps * eps, wt, d_last);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
 extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, float *corners,
                                 int count, int win_w, int win_h, int max_iters, double eps, int mem)
 {
@@ -95,16 +129,7 @@ extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int
     VO_REQUIRE(corners != nullptr, "vo_corner_subpix: corners is NULL");
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     SubpixWeights wt;
-    memset(&wt, 0, sizeof(wt));
-    const int ww = 2 * win_w + 1, wh = 2 * win_h + 1;
-    for (int i = 0; i < wh; ++i) {                      // the window weights, in float as OpenCV forms them
-        const float y = (float)(i - win_h) / win_h;
-        const float vy = expf(-y * y);
-        for (int j = 0; j < ww; ++j) {
-            const float x = (float)(j - win_w) / win_w;
-            wt.m[i * ww + j] = (float)(vy * expf(-x * x));
-        }
-    }
+    subpix_weights(wt, win_w, win_h);
     max_iters = max_iters < 1 ? 1 : (max_iters > 100 ? 100 : max_iters);
     eps = eps > 0 ? eps : 0;
     int rc;
@@ -123,7 +148,7 @@ extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int
         pitch = width;
     }
     hipLaunchKernelGGL(corner_subpix_kernel, dim3(count), dim3(64), 0, ctx->stream, d_img, height, width, pitch, d_c,
-                       count, win_w, win_h, max_iters, eps * eps, wt);
+                       count, win_w, win_h, max_iters, eps * eps, wt, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_HIP_CHECK(hipMemcpyAsync(corners, d_c, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));

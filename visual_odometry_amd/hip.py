@@ -567,6 +567,65 @@ def corner_subpix(ctx: Context, img, corners, win=(5, 5), max_iters: int = 50, e
     return out
 
 
+CC_FIRST_PIXEL = 0
+CC_FIRST_BLOCK = 1
+
+
+def connected_components(ctx: Context, mask, order: int = CC_FIRST_BLOCK, want_labels: bool = True):
+    """8-connected components of one uint8 mask (nonzero = foreground) with statistics, as
+    cv.connectedComponentsWithStats -> (n_labels, labels (H,W) int32 or None, centroids (n,2) float64 (x, y),
+    areas (n,) int32); label 0 is the background.  order: CC_FIRST_PIXEL or CC_FIRST_BLOCK numbering."""
+    n = ctypes.c_int32()
+    if _is_torch(mask):
+        import torch
+        if mask.dtype != torch.uint8 or mask.dim() != 2 or mask.stride(1) != 1:
+            raise ValueError("connected_components: device mask must be a 2-D uint8 tensor with unit pixel stride")
+        H, W = mask.shape
+        cap = ((H + 1) // 2) * ((W + 1) // 2) + 1
+        labels = torch.empty((H, W), dtype=torch.int32, device=mask.device) if want_labels else None
+        cen = torch.empty((cap, 2), dtype=torch.float64, device=mask.device)
+        areas = torch.empty(cap, dtype=torch.int32, device=mask.device)
+        rs, mem = mask.stride(0), VO_MEM_DEVICE
+    else:
+        mask = np.ascontiguousarray(mask, np.uint8)
+        if mask.ndim != 2:
+            raise ValueError("connected_components: mask must be 2-D")
+        H, W = mask.shape
+        cap = ((H + 1) // 2) * ((W + 1) // 2) + 1
+        labels = np.empty((H, W), np.int32) if want_labels else None
+        cen = np.empty((cap, 2), np.float64)
+        areas = np.empty(cap, np.int32)
+        rs, mem = W, VO_MEM_HOST
+    check(ctx.lib.vo_connected_components(ctx.handle, _ptr(mask), int(H), int(W), int(rs), int(order), _ptr(labels), _ptr(cen),
+                                          _ptr(areas), int(cap), ctypes.byref(n), mem), "vo_connected_components")
+    return int(n.value), labels, cen[:n.value], areas[:n.value]
+
+
+def harris_corners(ctx: Context, img, k: float = 0.1, rel_thresh: float = 0.01, order: int = CC_FIRST_BLOCK, win=(5, 5),
+                   max_iters: int = 50, eps: float = 0.001, max_corners: int = 0):
+    """FeatureExtractor.harris of the reference in one call: Harris mask, connected components, float32 centroids
+    (background first), cornerSubPix -> (M,2) float32 (x, y).  max_corners = 0: room for every possible label."""
+    n = ctypes.c_int32()
+    if _is_torch(img):
+        import torch
+        if img.dtype != torch.uint8 or img.dim() != 2 or img.stride(1) != 1:
+            raise ValueError("harris_corners: device image must be a 2-D uint8 tensor with unit pixel stride")
+        H, W = img.shape
+        cap = int(max_corners) or ((H + 1) // 2) * ((W + 1) // 2) + 1
+        out = torch.empty((cap, 2), dtype=torch.float32, device=img.device)
+        rs, mem = img.stride(0), VO_MEM_DEVICE
+    else:
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        cap = int(max_corners) or ((H + 1) // 2) * ((W + 1) // 2) + 1
+        out = np.empty((cap, 2), np.float32)
+        rs, mem = W, VO_MEM_HOST
+    check(ctx.lib.vo_harris_corners(ctx.handle, _ptr(img), int(H), int(W), int(rs), float(k), float(rel_thresh), int(order),
+                                    int(win[0]), int(win[1]), int(max_iters), float(eps), _ptr(out), int(cap), ctypes.byref(n),
+                                    mem), "vo_harris_corners")
+    return out[:min(int(n.value), cap)]
+
+
 def knn_match2(ctx: Context, des1, des2, ratio: float = 0.8):
     """Two nearest rows of des2 (n2,128) for every row of des1 (n1,128), exhaustive float32 L2 search.
     Returns (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8); keep = dist[:,0] < ratio * dist[:,1].

@@ -40,27 +40,17 @@ class FeatureExtractor:
         response with blockSize 2, ksize 3, k = 0.1; 3x3 dilation; threshold at 0.01 * max; 8-connected
         components of the mask; their centroids -- row 0 is the centroid of the background, as in the
         reference, whose connectedComponentsWithStats call returns label 0 first --; cornerSubPix with an
-        11x11 window, at most 50 iterations, eps 1e-3.  Response, mask and refinement run on the GPU
-        (vo_harris_mask, vo_corner_subpix); the labelling of the mask, a host step between them, uses
-        scipy.ndimage.label, which numbers the components in raster order of their first pixel."""
-        from scipy import ndimage
+        11x11 window, at most 50 iterations, eps 1e-3.  All of it is one library call (vo_harris_corners)
+        with one synchronisation.  Rows follow the numbering of the block-based labeller of the OpenCV
+        version the reference pins (components in raster order of their first 2x2 block); that order is
+        unpinned against cv2 itself, which is not installed here."""
         ctx = _runtime.context()
         gray = np.ascontiguousarray(img, dtype=np.uint8)
-        mask = hip.harris_mask(ctx, gray, 0.1, 0.01, hip.HARRIS)
-        labels, n = ndimage.label(mask, structure=np.ones((3, 3), np.int32))
-        # centroids from the foreground pixels only; the background's (label 0, first row as in the reference)
-        # follows from the totals over the whole image
-        h, w = gray.shape
-        ys, xs = np.nonzero(labels)
-        lab = labels[ys, xs]
-        area = np.bincount(lab, minlength=n + 1).astype(np.float64)
-        sx = np.bincount(lab, weights=xs, minlength=n + 1)
-        sy = np.bincount(lab, weights=ys, minlength=n + 1)
-        area[0] = h * w - ys.size
-        sx[0] = w * (w - 1) / 2.0 * h - xs.sum(dtype=np.float64)
-        sy[0] = h * (h - 1) / 2.0 * w - ys.sum(dtype=np.float64)
-        centroids = np.stack([sx, sy], axis=1) / np.maximum(area, 1)[:, None]
-        return hip.corner_subpix(ctx, gray, np.float32(centroids), (5, 5), 50, 0.001)
+        room = 4096                                  # a Harris mask rarely has more blobs; retry with full room if it does
+        corners = hip.harris_corners(ctx, gray, 0.1, 0.01, hip.CC_FIRST_BLOCK, (5, 5), 50, 0.001, max_corners=room)
+        if corners.shape[0] == room:
+            corners = hip.harris_corners(ctx, gray, 0.1, 0.01, hip.CC_FIRST_BLOCK, (5, 5), 50, 0.001)
+        return corners
 
     @staticmethod
     def harris_maxima(img: np.ndarray) -> np.ndarray:
