@@ -343,6 +343,32 @@ int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, int width, in
                       int order, int win_w, int win_h, int max_iters, double eps, float *corners, int max_corners,
                       int32_t *n_corners, int mem);
 
+/* ---- SIFT keypoints and descriptors ------------------------------------------------------------------
+ * vo_sift_detect_compute replaces cv.SIFT_create(nfeatures=0, nOctaveLayers, contrastThreshold,
+ * edgeThreshold, sigma).detectAndCompute(img, None) -- FeatureExtractor.get_kp,
+ * vo_pipeline/featureExtraction.py:20-35, called for both bootstrap images at
+ * vo_pipeline/bootstrap.py:179-181 (the reference's arguments: 4, 0.03, 10, 1.6).  One grayscale uint8
+ * image (follows `mem`).  keypoints: HOST array of max_keypoints records in OpenCV's KeyPoint fields
+ * (pt.x, pt.y, size, angle in degrees, response, octave packed as octave | layer << 8 | offset << 16),
+ * sorted and de-duplicated as cv2 returns them; descriptors (max_keypoints, 128) float32 with byte values
+ * (follows `mem`; may be NULL: detect only).  *n_keypoints (host) = keypoints found; only the first
+ * max_keypoints are written.  Synchronises the stream (keypoints are ordered on the host).
+ *
+ * vo_sift_scale_space_image (tests / debugging): builds the scale space of the image and copies one Gaussian
+ * (which = 0, index 0 .. layers + 2) or difference (which = 1, index 0 .. layers + 1) image of `octave` to the
+ * tight host buffer host_out (may be NULL to query the size).
+ */
+typedef struct vo_sift_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave;
+} vo_sift_keypoint;
+int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, int n_octave_layers,
+                           double contrast_threshold, double edge_threshold, double sigma, vo_sift_keypoint *keypoints,
+                           float *descriptors, int max_keypoints, int32_t *n_keypoints, int mem);
+int vo_sift_scale_space_image(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, int n_octave_layers,
+                              double sigma, int which, int octave, int index, float *host_out, int *out_width, int *out_height,
+                              int mem);
+
 /* ---- descriptor matching -----------------------------------------------------------------
  * vo_knn_match2 replaces matcher.knnMatch(des1, des2, k=2) inside
  * FeatureMatcher.match_descriptors (vo_pipeline/featureMatching.py:52-63) and the ratio test

@@ -35,6 +35,7 @@ def lib():
         _declare_match(_lib)
         _declare_subpix(_lib)
         _declare_cc(_lib)
+        _declare_sift(_lib)
     return _lib
 
 
@@ -95,6 +96,24 @@ def _declare_cc(L):
     L.vo_or_connected_components.restype = ctypes.c_int
     L.vo_or_connected_components.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _i32p, _f64p, _i32p,
                                              ctypes.c_int]
+
+
+SIFT_KP = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                    ("response", np.float32), ("octave", np.int32)])
+
+
+def _declare_sift(L):
+    L.vo_or_sift_detect_compute.restype = ctypes.c_int
+    L.vo_or_sift_detect_compute.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_void_p, _f32p, ctypes.c_int]
+    L.vo_or_sift_pyramid_image.restype = ctypes.c_int
+    L.vo_or_sift_pyramid_image.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, ctypes.POINTER(ctypes.c_int),
+                                           ctypes.POINTER(ctypes.c_int)]
+    L.vo_or_sift_num_octaves.restype = ctypes.c_int
+    L.vo_or_sift_num_octaves.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.vo_or_sift_gauss_kernel.restype = ctypes.c_int
+    L.vo_or_sift_gauss_kernel.argtypes = [ctypes.c_double, _f32p]
 
 
 def _declare_match(L):
@@ -294,3 +313,39 @@ def harris_corners(img, k=0.1, rel_thresh=0.01, order=1, win=(5, 5), max_iters=5
     mask = harris_mask(img, k, rel_thresh, 0)
     _, _, cen, _ = connected_components(mask, order)
     return corner_subpix(img, np.float32(cen), win, max_iters, eps)
+
+
+def sift(img, n_octave_layers=4, contrast_threshold=0.03, edge_threshold=10.0, sigma=1.6, max_keypoints=200000,
+         want_descriptors=True):
+    """cv.SIFT_create(0, layers, contrast, edge, sigma).detectAndCompute(img, None) restated ->
+    (keypoints: structured array SIFT_KP (x, y, size, angle, response, octave), descriptors (n,128) float32)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    kp = np.zeros(max_keypoints, SIFT_KP)
+    des = np.zeros((max_keypoints, 128), np.float32) if want_descriptors else None
+    n = lib().vo_or_sift_detect_compute(_p(img, _u8p), h, w, w, int(n_octave_layers), float(contrast_threshold),
+                                        float(edge_threshold), float(sigma), kp.ctypes.data,
+                                        _p(des, _f32p) if want_descriptors else None, max_keypoints)
+    n = min(n, max_keypoints)
+    return kp[:n].copy(), (des[:n].copy() if want_descriptors else None)
+
+
+def sift_pyramid_image(img, octave, index, dog=False, n_octave_layers=4, sigma=1.6):
+    """One image of the SIFT scale space: Gaussian (dog=False, index 0..layers+2) or difference (index 0..layers+1)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    n = lib().vo_or_sift_pyramid_image(_p(img, _u8p), h, w, w, int(n_octave_layers), float(sigma), int(dog), int(octave),
+                                       int(index), None, ctypes.byref(ow), ctypes.byref(oh))
+    if n < 0:
+        raise ValueError("sift_pyramid_image: no such image")
+    out = np.zeros((oh.value, ow.value), np.float32)
+    lib().vo_or_sift_pyramid_image(_p(img, _u8p), h, w, w, int(n_octave_layers), float(sigma), int(dog), int(octave),
+                                   int(index), _p(out, _f32p), ctypes.byref(ow), ctypes.byref(oh))
+    return out
+
+
+def sift_gauss_kernel(sigma):
+    k = np.zeros(64, np.float32)
+    n = lib().vo_or_sift_gauss_kernel(float(sigma), _p(k, _f32p))
+    return k[:n].copy()

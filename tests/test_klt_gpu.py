@@ -257,3 +257,17 @@ def test_klt_initial_estimates(oracle, ctx, klt_kernel):
     assert both.sum() > 300 and np.abs(out[0][both] - ro[both]).max() <= POS_TOL
     inside = both & (truth[:, 0] > 12) & (truth[:, 0] < w - 13) & (truth[:, 1] > 12) & (truth[:, 1] < h - 13)
     assert np.median(np.linalg.norm(out[0][inside] - truth[inside], axis=1)) < 0.1
+
+
+@pytest.mark.parametrize("shape,levels", [((768, 1024), 6), ((600, 800), 5)], ids=["malaga-1024x768", "malaga-800x600"])
+def test_klt_malaga_shapes_3000_keypoints(oracle, ctx, klt_kernel, shape, levels):
+    """The RANSAC configuration's frame sizes (1024x768 as quoted; 800x600 is what the reference's Malaga loader
+    reads, utils/loadData.py:79) with 3000 keypoints and the reference's maxLevel = 8, which the level-size rule
+    clamps to 5 and 4."""
+    from visual_odometry_amd import hip
+    img0, img1, _ = synth.frame_pair(shape, seed=77, max_shift=8.0)
+    pts = synth.uniform_keypoints(shape, 3000, seed=5, margin=4)
+    assert hip.Pyramid(ctx, 1, shape[0], shape[1], 8).max_level == levels - 1 == oracle.pyr_max_level(shape[1], shape[0], 8)
+    agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=8)
+    assert n_both > 2500
+    assert agree >= STATUS_AGREE and d <= POS_TOL, (agree, d)

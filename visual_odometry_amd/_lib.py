@@ -94,6 +94,12 @@ SIGNATURES = {
     "vo_harris_corners": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp,
                                          ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
+    "vo_sift_detect_compute": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_double, c_vp, c_vp, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
+    "vo_sift_scale_space_image": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(ctypes.c_int),
+                                                 ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "vo_knn_match2": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp, c_vp,
                                      c_vp, ctypes.c_int]),
 }

@@ -1,0 +1,705 @@
+// SIFT detect + describe: replaces cv.SIFT_create(0, 4, 0.03, 10, 1.6).detectAndCompute(img, None) of
+// FeatureExtractor.get_kp (vo_pipeline/featureExtraction.py:20-35), which the bootstrap calls on both images
+// (vo_pipeline/bootstrap.py:179-181).
+//
+// Algorithm: OpenCV 4.5.4's SIFT in its scalar form -- image doubled (bilinear) and blurred to sigma, Gaussian
+// scale space of layers + 3 images per octave, their differences, 26-neighbour extrema refined by Newton steps
+// with the contrast and edge tests, 36-bin orientation histograms (one keypoint per peak >= 0.8 max), keypoints
+// sorted and de-duplicated, 4x4x8 trilinear descriptors clamped at 0.2 and stored as saturated bytes in float32.
+// Every float expression keeps the operation order of the scalar algorithm (no contraction; exp and 2^x by a
+// fixed polynomial instead of a library call), so keypoints and descriptors equal a scalar evaluation bit for bit.
+//
+// Kernels (all HBM/L2-bound float32 streaming or small per-keypoint work; no contraction that would suit MFMA):
+//   sift_upsample_kernel     u8 -> float32, 2x bilinear
+//   sift_blur_rows/cols      separable Gaussian, REFLECT_101; rows add their taps left to right, columns in
+//                            symmetric pairs (the order of OpenCV's float row and column filters)
+//   sift_halve_kernel        next octave's base = every second pixel
+//   sift_dog_kernel          all differences of an octave in one launch
+//   sift_extrema_kernel      26-neighbour test over the four middle layers; candidates appended with one atomic
+//   sift_refine_kernel       one wavefront per candidate: Newton refinement (every lane, same values), orientation
+//                            histogram with lane b adding bin b's samples in raster order (deterministic float sums)
+//   sift_descriptor_kernel   one wavefront per keypoint: lanes form the samples of 64 window positions at a time,
+//                            compacted in raster order; lane c (0..35) owns spatial cell c of the 6x6x10 histogram
+//                            and adds the samples that touch it in that order
+// Sorting / de-duplication of the few thousand keypoints runs on the host between the two per-keypoint kernels.
+#include "vo_internal.h"
+#include <math.h>
+#include <algorithm>
+#include <vector>
+
+#define SIFT_IMG_BORDER 5
+#define SIFT_MAX_INTERP_STEPS 5
+#define SIFT_ORI_HIST_BINS 36
+#define SIFT_ORI_SIG_FCTR 1.5f
+#define SIFT_ORI_RADIUS (3 * SIFT_ORI_SIG_FCTR)
+#define SIFT_ORI_PEAK_RATIO 0.8f
+#define SIFT_DESCR_WIDTH 4
+#define SIFT_DESCR_HIST_BINS 8
+#define SIFT_DESCR_SCL_FCTR 3.f
+#define SIFT_DESCR_MAG_THR 0.2f
+#define SIFT_INT_DESCR_FCTR 512.f
+#define SIFT_INIT_SIGMA 0.5f
+#define SIFT_FLT_EPSILON 1.1920928955078125e-07f
+#define SIFT_MAX_OCTAVES 16
+#define SIFT_MAX_LAYERS 8
+#define SIFT_MAX_TAPS 63
+
+struct SiftKernel { int n; float k[SIFT_MAX_TAPS + 1]; };
+struct SiftCand { int octave, layer, r, c; };
+// descriptor job of one keypoint: image, rounded centre, rotation already divided by the histogram width
+struct SiftJob { int octave, layer, px, py, radius; float ori, cos_t, sin_t; };
+
+__host__ __device__ static inline int sift_floor(float v) { int i = (int)v; return i - (i > v); }
+
+// 2^t: integer part by exponent arithmetic, fraction by a degree-6 polynomial (relative error ~2e-7).
+__device__ static inline float sift_exp2(float t)
+{
+    if (t < -126.f) return 0.f;
+    float n = floorf(t), f = t - n;
+    float p = 1.530276e-4f;
+    p = p * f + 1.339887e-3f;
+    p = p * f + 9.618437e-3f;
+    p = p * f + 5.550357e-2f;
+    p = p * f + 2.402265e-1f;
+    p = p * f + 6.931472e-1f;
+    p = p * f + 1.0f;
+    return ldexpf(p, (int)n);
+}
+__device__ static inline float sift_exp(float x) { return sift_exp2(x * 1.44269504088896341f); }
+
+// OpenCV's fastAtan2 polynomial: degrees in [0, 360)
+__device__ static inline float sift_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f,
+                p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ static inline int sift_round_f(float v) { return (int)rintf(v); }     // to nearest, ties to even
+
+__device__ static inline int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t *__restrict__ img, int w, int h, int64_t stride,
+                                                           float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = 2 * w, H = 2 * h;
+    if (x >= W || y >= H) return;
+    float fy = (float)((y + 0.5) * 0.5 - 0.5);
+    int sy = sift_floor(fy);
+    fy -= sy;
+    if (sy < 0) { sy = 0; fy = 0; }
+    if (sy >= h - 1) { sy = h - 1; fy = 0; }
+    const int sy1 = sy + 1 < h ? sy + 1 : h - 1;
+    float fx = (float)((x + 0.5) * 0.5 - 0.5);
+    int sx = sift_floor(fx);
+    fx -= sx;
+    if (sx < 0) { sx = 0; fx = 0; }
+    if (sx >= w - 1) { sx = w - 1; fx = 0; }
+    const int sx1 = sx + 1 < w ? sx + 1 : w - 1;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float r0 = (float)img[sy * stride + sx] * a0 + (float)img[sy * stride + sx1] * a1;
+    const float r1 = (float)img[sy1 * stride + sx] * a0 + (float)img[sy1 * stride + sx1] * a1;
+    dst[(size_t)y * W + x] = r0 * b0 + r1 * b1;
+}
+
+// Row pass: a workgroup stages 256 + 2r pixels of one row in LDS (reflected at the ends), a lane adds its taps
+// left to right.
+__global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                            SiftKernel K)
+{
+    __shared__ float row[256 + SIFT_MAX_TAPS + 1];
+    const int y = blockIdx.y, x0 = blockIdx.x * 256, r = K.n >> 1;
+    const float *s = src + (size_t)y * w;
+    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) row[i] = s[reflect101(x0 - r + i, w)];
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    float acc = row[threadIdx.x] * K.k[0];
+    for (int j = 1; j < K.n; ++j) acc += row[threadIdx.x + j] * K.k[j];
+    dst[(size_t)y * w + x] = acc;
+}
+
+// Column pass: a lane owns a column and walks ROWS output rows, reading the 2r + 1 rows of each through the
+// cache (neighbouring lanes read neighbouring addresses); centre tap first, then symmetric pairs.
+#define SIFT_COL_ROWS 8
+__global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                            SiftKernel K)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SIFT_COL_ROWS, r = K.n >> 1;
+    if (x >= w) return;
+    for (int y = y0; y < min(y0 + SIFT_COL_ROWS, h); ++y) {
+        float acc = K.k[r] * src[(size_t)y * w + x];
+        for (int j = 1; j <= r; ++j)
+            acc += K.k[r + j] * (src[(size_t)reflect101(y + j, h) * w + x] + src[(size_t)reflect101(y - j, h) * w + x]);
+        dst[(size_t)y * w + x] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict__ src, int sw, float *__restrict__ dst, int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < w && y < h) dst[(size_t)y * w + x] = src[(size_t)(2 * y) * sw + 2 * x];
+}
+
+// dog[i] = gauss[i + 1] - gauss[i] for i = blockIdx.y; images of one octave are `plane` floats apart
+__global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__ gauss, float *__restrict__ dog, size_t plane)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= plane) return;
+    const float *a = gauss + plane * blockIdx.y;
+    dog[plane * blockIdx.y + t] = a[plane + t] - a[t];
+}
+
+__global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restrict__ dog, size_t plane, int w, int h, int octave,
+                                                          int threshold, SiftCand *__restrict__ cand, int *__restrict__ count,
+                                                          int cap)
+{
+    const int c = SIFT_IMG_BORDER + blockIdx.x * 64 + (threadIdx.x & 63), r = SIFT_IMG_BORDER + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int layer = 1 + blockIdx.z;
+    if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
+    const float *img = dog + plane * layer, *prev = img - plane, *next = img + plane;
+    const size_t at = (size_t)r * w + c;
+    const float val = img[at];
+    if (!(fabsf(val) > (float)threshold)) return;
+    bool is_max = val > 0, is_min = val < 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const size_t q = at + (size_t)((long)dy * w + dx);
+            const float a = prev[q], b = img[q], cc = next[q];
+            is_max = is_max && val >= a && val >= b && val >= cc;
+            is_min = is_min && val <= a && val <= b && val <= cc;
+        }
+    if (!is_max && !is_min) return;
+    const int slot = atomicAdd(count, 1);
+    if (slot < cap) cand[slot] = SiftCand{octave, layer, r, c};
+}
+
+struct SiftOctaves {
+    int n_oct, layers;
+    int w[SIFT_MAX_OCTAVES], h[SIFT_MAX_OCTAVES];
+    size_t gauss_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];   // float offsets into the pool
+};
+
+// One wavefront per candidate.
+#define SIFT_ORI_CHUNK 1024
+__global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftCand *__restrict__ cand,
+                                                        const int *__restrict__ n_cand, int cand_cap, float contrast_thr,
+                                                        float edge_thr, float sigma, vo_sift_keypoint *__restrict__ out,
+                                                        int *__restrict__ n_out, int out_cap)
+{
+    __shared__ float s_wm[SIFT_ORI_CHUNK];
+    __shared__ int s_bin[SIFT_ORI_CHUNK];
+    __shared__ float s_th[SIFT_ORI_HIST_BINS + 4];
+    const int lane = threadIdx.x;
+    const int total = min(*n_cand, cand_cap);
+    if ((int)blockIdx.x >= total) return;
+    const SiftCand cd = cand[blockIdx.x];
+    const int octv = cd.octave, w = O.w[octv], h = O.h[octv], nl = O.layers;
+    const size_t plane = (size_t)w * h;
+    const float *dogs = pool + O.dog_off[octv];
+    int layer = cd.layer, r = cd.r, c = cd.c;
+    const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second = img_scale, cross = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0;
+    for (; i < SIFT_MAX_INTERP_STEPS; ++i) {
+        const float *img = dogs + plane * layer, *prev = img - plane, *next = img + plane;
+        const size_t at = (size_t)r * w + c;
+        const float dD0 = (img[at + 1] - img[at - 1]) * deriv_scale, dD1 = (img[at + w] - img[at - w]) * deriv_scale,
+                    dD2 = (next[at] - prev[at]) * deriv_scale;
+        const float v2 = img[at] * 2;
+        const float dxx = (img[at + 1] + img[at - 1] - v2) * second, dyy = (img[at + w] + img[at - w] - v2) * second,
+                    dss = (next[at] + prev[at] - v2) * second;
+        const float dxy = (img[at + w + 1] - img[at + w - 1] - img[at - w + 1] + img[at - w - 1]) * cross;
+        const float dxs = (next[at + 1] - next[at - 1] - prev[at + 1] + prev[at - 1]) * cross;
+        const float dys = (next[at + w] - next[at - w] - prev[at + w] + prev[at - w]) * cross;
+        const float a00 = dxx, a01 = dxy, a02 = dxs, a10 = dxy, a11 = dyy, a12 = dys, a20 = dxs, a21 = dys, a22 = dss;
+        float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+        float X0 = 0, X1 = 0, X2 = 0;
+        if (d != 0) {
+            d = 1 / d;
+            X0 = d * (dD0 * (a11 * a22 - a12 * a21) - a01 * (dD1 * a22 - a12 * dD2) + a02 * (dD1 * a21 - a11 * dD2));
+            X1 = d * (a00 * (dD1 * a22 - a12 * dD2) - dD0 * (a10 * a22 - a12 * a20) + a02 * (a10 * dD2 - dD1 * a20));
+            X2 = d * (a00 * (a11 * dD2 - dD1 * a21) - a01 * (a10 * dD2 - dD1 * a20) + dD0 * (a10 * a21 - a11 * a20));
+        }
+        xi = -X2; xr = -X1; xc = -X0;
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(2147483647 / 3) || fabsf(xr) > (float)(2147483647 / 3) || fabsf(xc) > (float)(2147483647 / 3)) return;
+        c += sift_round_f(xc); r += sift_round_f(xr); layer += sift_round_f(xi);
+        if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= w - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER)
+            return;
+    }
+    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    vo_sift_keypoint kp;
+    {
+        const float *img = dogs + plane * layer, *prev = img - plane, *next = img + plane;
+        const size_t at = (size_t)r * w + c;
+        const float dD0 = (img[at + 1] - img[at - 1]) * deriv_scale, dD1 = (img[at + w] - img[at - w]) * deriv_scale,
+                    dD2 = (next[at] - prev[at]) * deriv_scale;
+        const float t = dD0 * xc + dD1 * xr + dD2 * xi;
+        const float contr = img[at] * img_scale + t * 0.5f;
+        if (fabsf(contr) * nl < contrast_thr) return;
+        const float v2 = img[at] * 2.f;
+        const float dxx = (img[at + 1] + img[at - 1] - v2) * second, dyy = (img[at + w] + img[at - w] - v2) * second;
+        const float dxy = (img[at + w + 1] - img[at + w - 1] - img[at - w + 1] + img[at - w - 1]) * cross;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return;
+        kp.x = (c + xc) * (1 << octv);
+        kp.y = (r + xr) * (1 << octv);
+        // cvRound((xi + 0.5) * 255) is a double expression in the scalar code
+        kp.octave = octv + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
+        kp.size = sigma * sift_exp2((layer + xi) / nl) * (1 << octv) * 2;
+        kp.response = fabsf(contr);
+    }
+    // ---- orientation histogram on the Gaussian image of the keypoint's layer ----
+    const float scl_octv = kp.size * 0.5f / (1 << octv);
+    const int radius = sift_round_f(SIFT_ORI_RADIUS * scl_octv);
+    const float osig = SIFT_ORI_SIG_FCTR * scl_octv, expf_scale = -1.f / (2.f * osig * osig);
+    const float *g = pool + O.gauss_off[octv] + plane * layer;
+    const int side = 2 * radius + 1, len = side * side;
+    const int n = SIFT_ORI_HIST_BINS;
+    float acc = 0.f;                                // lane b < 36: bin b
+    for (int base = 0; base < len; base += SIFT_ORI_CHUNK) {
+        const int m = min(SIFT_ORI_CHUNK, len - base);
+        for (int k = lane; k < m; k += 64) {
+            const int idx = base + k, i2 = idx / side - radius, j2 = idx % side - radius;
+            const int y = r + i2, x = c + j2;
+            int bin = -1;
+            float wm = 0.f;
+            if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+                const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1];
+                const float dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
+                const float wgt = sift_exp((i2 * i2 + j2 * j2) * expf_scale);
+                const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                bin = sift_round_f((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                wm = wgt * mag;
+            }
+            s_wm[k] = wm;
+            s_bin[k] = bin;
+        }
+        __syncthreads();
+        if (lane < n)
+            for (int k = 0; k < m; ++k)
+                if (s_bin[k] == lane) acc += s_wm[k];
+        __syncthreads();
+    }
+    if (lane < n) s_th[2 + lane] = acc;
+    __syncthreads();
+    if (lane == 0) { s_th[0] = s_th[2 + n - 2]; s_th[1] = s_th[2 + n - 1]; s_th[2 + n] = s_th[2]; s_th[2 + n + 1] = s_th[3]; }
+    __syncthreads();
+    const float *th = s_th + 2;
+    const int jl = lane < n ? lane : 0;
+    const float hj = (th[jl - 2] + th[jl + 2]) * (1.f / 16.f) + (th[jl - 1] + th[jl + 1]) * (4.f / 16.f) + th[jl] * (6.f / 16.f);
+    float omax = hj;                                // lanes >= 36 repeat bin 0: harmless for a maximum
+    for (int m2 = 32; m2 >= 1; m2 >>= 1) omax = fmaxf(omax, __shfl_xor(omax, m2));
+    const float mag_thr = omax * SIFT_ORI_PEAK_RATIO;
+    const float hl = __shfl(hj, lane > 0 ? lane - 1 : n - 1), hr = __shfl(hj, lane < n - 1 ? lane + 1 : 0);
+    if (lane < n && hj > hl && hj > hr && hj >= mag_thr) {
+        float bin = lane + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+        bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+        kp.angle = 360.f - (360.f / n) * bin;
+        if (fabsf(kp.angle - 360.f) < SIFT_FLT_EPSILON) kp.angle = 0.f;
+        const int slot = atomicAdd(n_out, 1);
+        if (slot < out_cap) out[slot] = kp;
+    }
+}
+
+// One wavefront per keypoint.  LDS: 6x6 cells x 10 orientation bins; a chunk of samples (cell, 8 weights each).
+#define SIFT_DESC_CHUNK 256
+__global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftJob *__restrict__ jobs,
+                                                            int n_jobs, float *__restrict__ desc)
+{
+    constexpr int d = SIFT_DESCR_WIDTH, n = SIFT_DESCR_HIST_BINS;
+    __shared__ float hist[(d + 2) * (d + 2) * (n + 2)];
+    __shared__ float s_v[SIFT_DESC_CHUNK][8];
+    __shared__ int s_cell[SIFT_DESC_CHUNK];
+    __shared__ float s_dst[d * d * n];
+    __shared__ float s_scale[2];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_jobs) return;
+    const SiftJob jb = jobs[blockIdx.x];
+    const int w = O.w[jb.octave], h = O.h[jb.octave];
+    const float *img = pool + O.gauss_off[jb.octave] + (size_t)w * h * jb.layer;
+    for (int t = lane; t < (d + 2) * (d + 2) * (n + 2); t += 64) hist[t] = 0.f;
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
+    const int radius = jb.radius, side = 2 * radius + 1, len = side * side;
+    const int my_r = lane / (d + 2), my_c = lane % (d + 2);        // the cell lane < 36 owns
+    int filled = 0;                                                 // samples waiting in the chunk (wave-uniform)
+    __syncthreads();
+    for (int base = 0; base < len; base += 64) {
+        const int idx = base + lane;
+        bool ok = false;
+        float v[8];
+        int cell = 0;
+        if (idx < len) {
+            const int i = idx / side - radius, j = idx % side - radius;
+            const float c_rot = j * jb.cos_t - i * jb.sin_t, r_rot = j * jb.sin_t + i * jb.cos_t;
+            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = jb.py + i, c = jb.px + j;
+            ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+            if (ok) {
+                const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
+                const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
+                const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                float obin = (sift_atan2_deg(dy, dx) - jb.ori) * bins_per_rad;
+                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+                const int r0 = sift_floor(rbin), c0 = sift_floor(cbin);
+                int o0 = sift_floor(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7];      // [r][c][o] -> index 4r + 2c + o
+                v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
+                v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
+                v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
+                cell = ((r0 + 1) << 16) | ((c0 + 1) << 8) | o0;
+            }
+        }
+        // compact in raster order behind the samples already waiting
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int at = filled + __popcll(m & ((1ull << lane) - 1ull));
+            s_cell[at] = cell;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_v[at][q] = v[q];
+        }
+        filled += __popcll(m);
+        if (filled > SIFT_DESC_CHUNK - 64 || base + 64 >= len) {
+            // the owner of a cell adds the waiting samples that touch it, in their (raster) order
+            __syncthreads();
+            if (lane < (d + 2) * (d + 2)) {
+                float *mine = hist + lane * (n + 2);
+                for (int sidx = 0; sidx < filled; ++sidx) {
+                    const int cl = s_cell[sidx];
+                    const int dr = my_r - (cl >> 16), dc = my_c - ((cl >> 8) & 255);
+                    if ((unsigned)dr < 2u && (unsigned)dc < 2u) {
+                        const int o0 = cl & 255, q = 4 * dr + 2 * dc;
+                        mine[o0] += s_v[sidx][q];
+                        mine[o0 + 1] += s_v[sidx][q + 1];
+                    }
+                }
+            }
+            __syncthreads();
+            filled = 0;
+        }
+    }
+    __syncthreads();
+    // circular orientation bins, then the 128 values
+    if (lane < d * d) {
+        const int i = lane / d, j = lane % d;
+        float *hc = hist + ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+        hc[0] += hc[n];
+        hc[1] += hc[n + 1];
+        for (int k = 0; k < n; ++k) s_dst[(i * d + j) * n + k] = hc[k];
+    }
+    __syncthreads();
+    constexpr int L = d * d * n;
+    if (lane == 0) {
+        float nrm2 = 0;
+        for (int k = 0; k < L; ++k) nrm2 += s_dst[k] * s_dst[k];
+        const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
+        nrm2 = 0;
+        for (int k = 0; k < L; ++k) {
+            const float v = s_dst[k] < thr ? s_dst[k] : thr;
+            nrm2 += v * v;
+        }
+        const float sq = sqrtf(nrm2);
+        s_scale[0] = thr;
+        s_scale[1] = SIFT_INT_DESCR_FCTR / (sq > SIFT_FLT_EPSILON ? sq : SIFT_FLT_EPSILON);
+    }
+    __syncthreads();
+    for (int k = lane; k < L; k += 64) {
+        const float v = s_dst[k] < s_scale[0] ? s_dst[k] : s_scale[0];
+        int q = sift_round_f(v * s_scale[1]);
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        desc[(size_t)blockIdx.x * L + k] = (float)q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int sift_gauss_kernel(double sigma, SiftKernel &K)
+{
+    int n = (int)lrint(sigma * 8 + 1) | 1;
+    VO_REQUIRE(n <= SIFT_MAX_TAPS, "SIFT: sigma %g needs a %d-tap Gaussian (at most %d)", sigma, n, SIFT_MAX_TAPS);
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        K.k[i] = (float)exp(s2 * x * x);
+        sum += K.k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) K.k[i] = (float)(K.k[i] * sum);
+    K.n = n;
+    return VO_OK;
+}
+
+static int sift_blur(vo_ctx *ctx, const float *src, float *dst, float *tmp, int w, int h, double sigma)
+{
+    SiftKernel K;
+    int rc = sift_gauss_kernel(sigma, K);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sift_blur_rows_kernel, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, tmp, w, h, K);
+    hipLaunchKernelGGL(sift_blur_cols_kernel, dim3((w + 255) / 256, (h + SIFT_COL_ROWS - 1) / SIFT_COL_ROWS), dim3(256), 0, ctx->stream,
+                       (const float *)tmp, dst, w, h, K);
+    return VO_OK;
+}
+
+struct SiftSpace {
+    SiftOctaves O;
+    float *pool = nullptr;      // Gaussian and difference images (context slot 1)
+    float *tmp = nullptr;       // row-pass output / doubled input (context slot 2)
+};
+
+static int sift_num_octaves(int w, int h)
+{
+    const int m = 2 * (w < h ? w : h);
+    return (int)lrint(log((double)m) / log(2.) - 2) + 1;
+}
+
+// Scale space of one image (device pointer d_img) in the context's buffers; asynchronous.
+static int sift_build(vo_ctx *ctx, const uint8_t *d_img, int height, int width, int64_t pitch, int layers, double sigma, SiftSpace &S)
+{
+    SiftOctaves &O = S.O;
+    O.layers = layers;
+    O.n_oct = sift_num_octaves(width, height);
+    VO_REQUIRE(O.n_oct >= 1 && O.n_oct <= SIFT_MAX_OCTAVES, "SIFT: %d octaves for a %d x %d image", O.n_oct, width, height);
+    const int W = 2 * width, H = 2 * height;
+    size_t total = 0;
+    for (int o = 0; o < O.n_oct; ++o) {
+        O.w[o] = o == 0 ? W : O.w[o - 1] / 2;
+        O.h[o] = o == 0 ? H : O.h[o - 1] / 2;
+        VO_REQUIRE(O.w[o] >= 1 && O.h[o] >= 1, "SIFT: octave %d of a %d x %d image is empty", o, width, height);
+        const size_t plane = (size_t)O.w[o] * O.h[o];
+        O.gauss_off[o] = total; total += plane * (layers + 3);
+        O.dog_off[o] = total; total += plane * (layers + 2);
+    }
+    int rc;
+    void *p;
+    if ((rc = vo_stage_reserve(ctx, 1, total * 4, &p))) return rc; S.pool = (float *)p;
+    if ((rc = vo_stage_reserve(ctx, 2, (size_t)W * H * 8, &p))) return rc; S.tmp = (float *)p;
+    float *dbl = S.tmp + (size_t)W * H;
+    hipLaunchKernelGGL(sift_upsample_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, ctx->stream, d_img, width, height, pitch, dbl);
+    double sig[SIFT_MAX_LAYERS + 3];
+    sig[0] = sigma;
+    const double k = pow(2., 1. / layers);
+    for (int i = 1; i < layers + 3; ++i) {
+        const double sp = pow(k, (double)(i - 1)) * sigma, st = sp * k;
+        sig[i] = sqrt(st * st - sp * sp);
+    }
+    double sd = sigma * sigma - (double)(SIFT_INIT_SIGMA * 2) * (SIFT_INIT_SIGMA * 2);
+    sd = sqrt(sd > 0.01 ? sd : 0.01);
+    for (int o = 0; o < O.n_oct; ++o) {
+        const int ow = O.w[o], oh = O.h[o];
+        const size_t plane = (size_t)ow * oh;
+        float *g = S.pool + O.gauss_off[o];
+        for (int i = 0; i < layers + 3; ++i) {
+            float *dst = g + plane * i;
+            if (o == 0 && i == 0) { if ((rc = sift_blur(ctx, dbl, dst, S.tmp, ow, oh, sd))) return rc; }
+            else if (i == 0)
+                hipLaunchKernelGGL(sift_halve_kernel, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, ctx->stream,
+                                   (const float *)(S.pool + O.gauss_off[o - 1] + (size_t)O.w[o - 1] * O.h[o - 1] * layers), O.w[o - 1], dst, ow, oh);
+            else if ((rc = sift_blur(ctx, dst - plane, dst, S.tmp, ow, oh, sig[i]))) return rc;
+        }
+        hipLaunchKernelGGL(sift_dog_kernel, dim3((unsigned)((plane + 255) / 256), layers + 2), dim3(256), 0, ctx->stream, (const float *)g,
+                           S.pool + O.dog_off[o], plane);
+    }
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+static int sift_check_args(const char *who, vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, int layers,
+                           double sigma, int mem)
+{
+    VO_REQUIRE(ctx && img, "%s: NULL argument", who);
+    VO_REQUIRE(height >= 2 && width >= 2 && row_stride >= width && (int64_t)height * width < (1ll << 28), "%s: bad shape h=%d w=%d", who,
+               height, width);
+    VO_REQUIRE(layers >= 1 && layers <= SIFT_MAX_LAYERS, "%s: n_octave_layers=%d (1..%d)", who, layers, SIFT_MAX_LAYERS);
+    VO_REQUIRE(sigma > 0.1 && sigma < 7, "%s: sigma=%g", who, sigma);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "%s: bad mem flag %d", who, mem);
+    return VO_OK;
+}
+
+static int sift_stage_image(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride, int mem, const uint8_t **d_img,
+                            int64_t *pitch)
+{
+    *d_img = img; *pitch = row_stride;
+    if (mem == VO_MEM_DEVICE) return VO_OK;
+    void *p;
+    int rc = vo_stage_reserve(ctx, 0, (size_t)width * height, &p);
+    if (rc) return rc;
+    if (row_stride == width)
+        VO_HIP_CHECK(hipMemcpyAsync(p, img, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+    else
+        VO_HIP_CHECK(hipMemcpy2DAsync(p, width, img, row_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    *d_img = (const uint8_t *)p; *pitch = width;
+    return VO_OK;
+}
+
+extern "C" int vo_sift_scale_space_image(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride,
+                                         int n_octave_layers, double sigma, int which, int octave, int index, float *host_out,
+                                         int *out_width, int *out_height, int mem)
+{
+    int rc = sift_check_args("vo_sift_scale_space_image", ctx, img, height, width, row_stride, n_octave_layers, sigma, mem);
+    if (rc) return rc;
+    VO_REQUIRE(out_width && out_height, "vo_sift_scale_space_image: NULL size outputs");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint8_t *d_img;
+    int64_t pitch;
+    if ((rc = sift_stage_image(ctx, img, height, width, row_stride, mem, &d_img, &pitch))) return rc;
+    SiftSpace S;
+    if ((rc = sift_build(ctx, d_img, height, width, pitch, n_octave_layers, sigma, S))) return rc;
+    VO_REQUIRE(octave >= 0 && octave < S.O.n_oct && index >= 0 && index < n_octave_layers + (which ? 2 : 3),
+               "vo_sift_scale_space_image: no image (octave %d of %d, index %d)", octave, S.O.n_oct, index);
+    *out_width = S.O.w[octave]; *out_height = S.O.h[octave];
+    const size_t plane = (size_t)S.O.w[octave] * S.O.h[octave];
+    if (host_out) {
+        const float *src = S.pool + (which ? S.O.dog_off[octave] : S.O.gauss_off[octave]) + plane * index;
+        VO_HIP_CHECK(hipMemcpyAsync(host_out, src, plane * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int height, int width, int64_t row_stride,
+                                      int n_octave_layers, double contrast_threshold, double edge_threshold, double sigma,
+                                      vo_sift_keypoint *keypoints, float *descriptors, int max_keypoints, int32_t *n_keypoints,
+                                      int mem)
+{
+    int rc = sift_check_args("vo_sift_detect_compute", ctx, img, height, width, row_stride, n_octave_layers, sigma, mem);
+    if (rc) return rc;
+    VO_REQUIRE(n_keypoints && max_keypoints >= 0 && (max_keypoints == 0 || keypoints), "vo_sift_detect_compute: NULL output");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint8_t *d_img;
+    int64_t pitch;
+    if ((rc = sift_stage_image(ctx, img, height, width, row_stride, mem, &d_img, &pitch))) return rc;
+    SiftSpace S;
+    if ((rc = sift_build(ctx, d_img, height, width, pitch, n_octave_layers, sigma, S))) return rc;
+    const SiftOctaves &O = S.O;
+
+    // candidates and raw keypoints: counters | candidates | keypoints (context slot 3)
+    const int cand_cap = 1 << 19, kp_cap = 1 << 18;
+    void *p;
+    if ((rc = vo_stage_reserve(ctx, 3, 256 + (size_t)cand_cap * sizeof(SiftCand) + (size_t)kp_cap * sizeof(vo_sift_keypoint), &p))) return rc;
+    int *d_cnt = (int *)p;
+    SiftCand *d_cand = (SiftCand *)((char *)p + 256);
+    vo_sift_keypoint *d_kp = (vo_sift_keypoint *)((char *)p + 256 + (size_t)cand_cap * sizeof(SiftCand));
+    VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+    const int threshold = (int)floor(0.5 * contrast_threshold / n_octave_layers * 255);
+    for (int o = 0; o < O.n_oct; ++o) {
+        const int ow = O.w[o], oh = O.h[o];
+        if (ow <= 2 * SIFT_IMG_BORDER || oh <= 2 * SIFT_IMG_BORDER) continue;
+        hipLaunchKernelGGL(sift_extrema_kernel, dim3((ow - 2 * SIFT_IMG_BORDER + 63) / 64, (oh - 2 * SIFT_IMG_BORDER + 3) / 4, n_octave_layers),
+                           dim3(256), 0, ctx->stream, (const float *)(S.pool + O.dog_off[o]), (size_t)ow * oh, ow, oh, o, threshold,
+                           d_cand, d_cnt, cand_cap);
+    }
+    VO_HIP_CHECK(hipGetLastError());
+    int h_cnt[2] = {0, 0};
+    VO_HIP_CHECK(hipMemcpyAsync(h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (h_cnt[0] > cand_cap) { vo_set_error("vo_sift_detect_compute: %d scale-space extrema exceed the candidate buffer (%d)", h_cnt[0], cand_cap); return VO_ESTATE; }
+    if (h_cnt[0] > 0) {
+        hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
+                           (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp, d_cnt + 1, kp_cap);
+        VO_HIP_CHECK(hipGetLastError());
+    }
+    VO_HIP_CHECK(hipMemcpyAsync(h_cnt + 1, d_cnt + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
+    std::vector<vo_sift_keypoint> kps((size_t)h_cnt[1]);
+    if (h_cnt[1]) {
+        VO_HIP_CHECK(hipMemcpyAsync(kps.data(), d_kp, kps.size() * sizeof(vo_sift_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    // KeyPointsFilter::removeDuplicatedSorted: order by (x, y, size desc, angle, response desc, octave desc), drop repeats
+    std::sort(kps.begin(), kps.end(), [](const vo_sift_keypoint &a, const vo_sift_keypoint &b) {
+        if (a.x != b.x) return a.x < b.x;
+        if (a.y != b.y) return a.y < b.y;
+        if (a.size != b.size) return a.size > b.size;
+        if (a.angle != b.angle) return a.angle < b.angle;
+        if (a.response != b.response) return a.response > b.response;
+        return a.octave > b.octave;
+    });
+    size_t m = 0;
+    for (size_t i = 0; i < kps.size(); ++i) {
+        if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle)
+            continue;
+        kps[m++] = kps[i];
+    }
+    kps.resize(m);
+    const int first_octave = -1;
+    for (auto &k : kps) {       // back to the coordinates of the input image (the scale space starts at the doubled image)
+        k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+        k.x *= 0.5f; k.y *= 0.5f; k.size *= 0.5f;
+    }
+    *n_keypoints = (int32_t)m;
+    const size_t n_out = m < (size_t)max_keypoints ? m : (size_t)max_keypoints;
+    for (size_t i = 0; i < n_out; ++i) keypoints[i] = kps[i];
+    if (!descriptors || n_out == 0) return VO_OK;
+
+    std::vector<SiftJob> jobs(n_out);
+    constexpr int d = SIFT_DESCR_WIDTH;
+    for (size_t i = 0; i < n_out; ++i) {
+        int octave = kps[i].octave & 255;
+        const int layer = (kps[i].octave >> 8) & 255;
+        octave = octave < 128 ? octave : (-128 | octave);
+        const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+        const float size = kps[i].size * scale, scl = size * 0.5f;
+        const float ptx = kps[i].x * scale, pty = kps[i].y * scale;
+        float angle = 360.f - kps[i].angle;
+        if (fabsf(angle - 360.f) < SIFT_FLT_EPSILON) angle = 0.f;
+        SiftJob &jb = jobs[i];
+        jb.octave = octave - first_octave;
+        jb.layer = layer;
+        jb.px = (int)lrint((double)ptx);
+        jb.py = (int)lrint((double)pty);
+        jb.ori = angle;
+        float cos_t = (float)cos((double)(angle * (float)(3.14159265358979323846 / 180.))),
+              sin_t = (float)sin((double)(angle * (float)(3.14159265358979323846 / 180.)));
+        const float hist_width = SIFT_DESCR_SCL_FCTR * scl;
+        int radius = (int)lrint((double)(hist_width * 1.4142135623730951f * (d + 1) * 0.5f));
+        const int w = O.w[jb.octave], h = O.h[jb.octave];
+        const int rmax = (int)sqrt((double)w * w + (double)h * h);
+        jb.radius = radius < rmax ? radius : rmax;
+        jb.cos_t = cos_t / hist_width;
+        jb.sin_t = sin_t / hist_width;
+    }
+    if ((rc = vo_stage_reserve(ctx, 4, n_out * sizeof(SiftJob), &p))) return rc;
+    SiftJob *d_jobs = (SiftJob *)p;
+    float *d_desc = descriptors;
+    if (mem == VO_MEM_HOST) {
+        if ((rc = vo_stage_reserve(ctx, 5, n_out * 128 * 4, &p))) return rc;
+        d_desc = (float *)p;
+    }
+    // pageable source: the copy is staged before the call returns, so `jobs` may go out of scope afterwards
+    VO_HIP_CHECK(hipMemcpy(d_jobs, jobs.data(), n_out * sizeof(SiftJob), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)n_out), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
+                       (const SiftJob *)d_jobs, (int)n_out, d_desc);
+    VO_HIP_CHECK(hipGetLastError());
+    if (mem == VO_MEM_HOST) {
+        VO_HIP_CHECK(hipMemcpyAsync(descriptors, d_desc, n_out * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}

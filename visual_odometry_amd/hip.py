@@ -626,6 +626,51 @@ def harris_corners(ctx: Context, img, k: float = 0.1, rel_thresh: float = 0.01, 
     return out[:min(int(n.value), cap)]
 
 
+SIFT_KEYPOINT = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                          ("response", np.float32), ("octave", np.int32)])
+
+
+def sift_detect_compute(ctx: Context, img, n_octave_layers: int = 4, contrast_threshold: float = 0.03, edge_threshold: float = 10.0,
+                        sigma: float = 1.6, max_keypoints: int = 65536, want_descriptors: bool = True):
+    """SIFT keypoints and descriptors of one grayscale uint8 image, as cv.SIFT_create(0, layers, contrast, edge,
+    sigma).detectAndCompute(img, None) -> (keypoints: structured numpy array SIFT_KEYPOINT, descriptors (n,128) float32
+    -- numpy for a numpy image, a GPU tensor for a GPU image -- or None)."""
+    n = ctypes.c_int32()
+    kp = np.empty(int(max_keypoints), SIFT_KEYPOINT)
+    if _is_torch(img):
+        import torch
+        if img.dtype != torch.uint8 or img.dim() != 2 or img.stride(1) != 1:
+            raise ValueError("sift_detect_compute: device image must be a 2-D uint8 tensor with unit pixel stride")
+        H, W = img.shape
+        des = torch.empty((int(max_keypoints), 128), dtype=torch.float32, device=img.device) if want_descriptors else None
+        rs, mem = img.stride(0), VO_MEM_DEVICE
+    else:
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim != 2:
+            raise ValueError("sift_detect_compute: image must be 2-D")
+        H, W = img.shape
+        des = np.empty((int(max_keypoints), 128), np.float32) if want_descriptors else None
+        rs, mem = W, VO_MEM_HOST
+    check(ctx.lib.vo_sift_detect_compute(ctx.handle, _ptr(img), int(H), int(W), int(rs), int(n_octave_layers),
+                                         float(contrast_threshold), float(edge_threshold), float(sigma), _ptr(kp), _ptr(des),
+                                         int(max_keypoints), ctypes.byref(n), mem), "vo_sift_detect_compute")
+    m = min(int(n.value), int(max_keypoints))
+    return kp[:m], (des[:m] if want_descriptors else None)
+
+
+def sift_scale_space_image(ctx: Context, img, octave: int, index: int, dog: bool = False, n_octave_layers: int = 4,
+                           sigma: float = 1.6) -> np.ndarray:
+    """One image of the SIFT scale space (tests / debugging): Gaussian, or difference of Gaussians with dog=True."""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    ow, oh = ctypes.c_int(), ctypes.c_int()
+    args = (ctx.handle, _ptr(img), int(H), int(W), int(W), int(n_octave_layers), float(sigma), int(dog), int(octave), int(index))
+    check(ctx.lib.vo_sift_scale_space_image(*args, None, ctypes.byref(ow), ctypes.byref(oh), VO_MEM_HOST), "vo_sift_scale_space_image")
+    out = np.empty((oh.value, ow.value), np.float32)
+    check(ctx.lib.vo_sift_scale_space_image(*args, _ptr(out), ctypes.byref(ow), ctypes.byref(oh), VO_MEM_HOST), "vo_sift_scale_space_image")
+    return out
+
+
 def knn_match2(ctx: Context, des1, des2, ratio: float = 0.8):
     """Two nearest rows of des2 (n2,128) for every row of des1 (n1,128), exhaustive float32 L2 search.
     Returns (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8); keep = dist[:,0] < ratio * dist[:,1].

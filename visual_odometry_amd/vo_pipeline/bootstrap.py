@@ -1,12 +1,11 @@
 """BootstrapInitializer -- two-view initialisation with the reference's API and
 attributes (vo_pipeline/bootstrap.py:13-261).
 
-Differences that follow from the scope of this build: SIFT is not computed here.  By
-default correspondences come from Shi-Tomasi corners tracked with the pyramidal LK
-kernel (descriptors pts_des1/pts_des2 are then zero-filled (n,128) arrays); a caller
-that has keypoints and descriptors of both images passes them as `features` and gets
-the reference's route, two-nearest-neighbour matching with the ratio test
-(bootstrap.py:188-211), on the GPU.  The fundamental matrix comes from
+Correspondences come, as in the reference (bootstrap.py:179-211), from SIFT keypoints of both
+images matched by two nearest neighbours with the ratio test, all on the GPU; a caller that
+already has keypoints and descriptors passes them as `features`.  `correspondences="klt"`
+selects the lighter route of the project statement instead: Shi-Tomasi corners tracked with the
+pyramidal LK kernel (descriptors pts_des1/pts_des2 are then zero-filled (n,128) arrays).  The fundamental matrix comes from
 ransac.find_fundamental_mat (GPU-scored RANSAC) instead of cv2.findFundamentalMat.  The two-view geometry after F (motion hypotheses, cheirality vote, feasibility mask) is this
 build's own formulation of bootstrap.py:76-138 with the vote on the GPU; its outputs are pinned by
 tests/golden/two_view.npz (outputs of the reference functions).
@@ -24,10 +23,15 @@ from .poseEstimation import PoseEstimation
 
 
 class BootstrapInitializer:
-    def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100, features=None):
+    def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100, features=None,
+                 correspondences: str = "sift"):
         """features: optional (kp0, des0, kp1, des1) -- keypoints of the two images as (n,2) arrays of (x, y) or
-        sequences of objects with a `.pt`, and their (n,128) descriptors."""
+        sequences of objects with a `.pt`, and their (n,128) descriptors.  correspondences: "sift" (the reference's
+        route) or "klt" (corners + tracking), used when no features are given."""
+        if correspondences not in ("sift", "klt"):
+            raise ValueError(f"BootstrapInitializer: correspondences must be 'sift' or 'klt', got {correspondences!r}")
         self.features = features
+        self.correspondences = correspondences
         self.img1 = img1
         self.img2 = img2
         self.K = K
@@ -72,6 +76,10 @@ class BootstrapInitializer:
         return kp0[q], kp1[t], np.asarray(des0, np.float32)[q], np.asarray(des1, np.float32)[t]
 
     def _estimate_fundamental(self, normalize=False):
+        if self.features is None and self.correspondences == "sift":
+            k0, d0 = FeatureExtractor.sift_arrays(self.img1)
+            k1, d1 = FeatureExtractor.sift_arrays(self.img2)
+            self.features = (np.stack([k0["x"], k0["y"]], axis=1), d0, np.stack([k1["x"], k1["y"]], axis=1), d1)
         if self.features is not None:
             kp0, kp1, des0, des1 = self._matched_features()
             return self._fundamental_from(kp0, kp1, des0, des1)

@@ -91,9 +91,9 @@ def window_indices(traj_per_frame: Sequence[np.ndarray]) -> Tuple[np.ndarray, np
 
 
 class ContinuousVO:
-    """Same constructor, attributes and step() protocol as the reference.  descriptorType /
-    matcherType are accepted for signature compatibility; correspondences always come from the
-    corner detector + KLT (SIFT and descriptor matching are not part of this build).
+    """Same constructor, attributes and step() protocol as the reference.  Bootstraps take their
+    correspondences from SIFT + two-nearest-neighbour matching like the reference
+    (bootstrap_correspondences="sift"), or from Shi-Tomasi corners tracked by KLT ("klt").
 
     rescale_bootstrap: a re-bootstrap triangulates with a unit baseline (bootstrap.py:103-111).
     False (default) is the reference's active code path: every keyframe restarts the scale.  True is
@@ -103,7 +103,8 @@ class ContinuousVO:
 
     def __init__(self, dataset, descriptorType=ExtractorType.SIFT, matcherType=None, useKLT=True,
                  algo_method=AlgoMethod.P3P, max_point_distance: int = 100, frames_to_skip: int = 10,
-                 frame_queue_size: int = 1000, rescale_bootstrap: bool = False) -> None:
+                 frame_queue_size: int = 1000, rescale_bootstrap: bool = False,
+                 bootstrap_correspondences: str = "sift") -> None:
         self.dataset = dataset
         self.descriptor = FeatureExtractor(descriptorType)
         self.matcher = matcherType
@@ -117,6 +118,7 @@ class ContinuousVO:
         self.max_point_distance = max_point_distance
         self.frames_to_skip = frames_to_skip
         self.rescale_bootstrap = rescale_bootstrap
+        self.bootstrap_correspondences = bootstrap_correspondences
         self.keypoint_trajectories = KeypointTrajectories()
         self.frame_idx = 0
         self.bootstrap_idx: List[int] = []
@@ -154,7 +156,8 @@ class ContinuousVO:
                    world_transform: Optional[np.ndarray] = None) -> np.ndarray:
         """Two-view initialisation between baseline and img; registers one trajectory per
         triangulated point on frame_idx.  Returns the world -> camera transform of img."""
-        bootstrap = BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance)
+        bootstrap = BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance,
+                                         correspondences=self.bootstrap_correspondences)
         T_rel = np.array(bootstrap.T)
         landmarks = np.array(bootstrap.point_cloud)
         if self.rescale_bootstrap and world_transform is not None:

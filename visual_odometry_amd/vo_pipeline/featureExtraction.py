@@ -12,18 +12,46 @@ class ExtractorType(enum.Enum):
     SIFT = 0,
 
 
+class KeyPoint:
+    """The fields of cv2.KeyPoint that the pipeline reads (bootstrap.py:208-209 uses `.pt`)."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x: float, y: float, size: float, angle: float = -1.0, response: float = 0.0, octave: int = 0,
+                 class_id: int = -1):
+        self.pt = (float(x), float(y))
+        self.size, self.angle, self.response = float(size), float(angle), float(response)
+        self.octave, self.class_id = int(octave), int(class_id)
+
+    def __repr__(self) -> str:
+        return f"KeyPoint(pt={self.pt}, size={self.size:.3f}, angle={self.angle:.2f}, response={self.response:.4f}, octave={self.octave})"
+
+
 class FeatureExtractor:
     """Computes image features for a given ExtractorType."""
+
+    # the reference's SIFT arguments (featureExtraction.py:22-26)
+    SIFT_ARGS = dict(n_octave_layers=4, contrast_threshold=0.03, edge_threshold=10.0, sigma=1.6)
 
     def __init__(self, extractor_type: ExtractorType = ExtractorType.SIFT):
         self.extractor_type = extractor_type
         self.extractor = None
+        self.get_extractor()
+
+    def get_extractor(self) -> None:
+        if self.extractor_type == ExtractorType.SIFT:
+            self.extractor = self.sift_arrays
+
+    @classmethod
+    def sift_arrays(cls, img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """SIFT on the GPU -> (keypoints as a structured array (x, y, size, angle, response, octave), descriptors
+        (n, 128) float32): the array form of get_kp, without one Python object per keypoint."""
+        return hip.sift_detect_compute(_runtime.context(), np.ascontiguousarray(img, dtype=np.uint8), **cls.SIFT_ARGS)
 
     def get_kp(self, img: np.ndarray) -> Tuple[List[Any], np.ndarray]:
-        """SIFT detect+describe (featureExtraction.py:20-35) is outside the accelerated
-        path: descriptors are not produced by this build."""
-        raise NotImplementedError("SIFT descriptors are not part of the GPU front end; "
-                                  "use FeatureExtractor.harris / corners() for keypoints")
+        """Keypoints and (num_keypoints, 128) float32 descriptors of img (featureExtraction.py:28-35):
+        cv.SIFT_create(0, 4, 0.03, 10, 1.6).detectAndCompute(img, None), computed by vo_sift_detect_compute."""
+        kp, des = self.extractor(img)
+        return [KeyPoint(k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"]) for k in kp], des
 
     @staticmethod
     def corners(img: np.ndarray, max_corners: int = 2000, quality: float = 0.01, radius: int = 5,
