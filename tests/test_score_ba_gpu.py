@@ -71,8 +71,17 @@ def test_score_device_buffers_and_empty(oracle, ctx):
         hip.score_fundamental(ctx, sc["m1"], sc["m2"][:10], Fh, 0.1)
 
 
+@pytest.fixture(params=["atomics", "gather"])
+def landmark_path(request, monkeypatch):
+    """vo_ba_normal_eq sums the landmark blocks with float64 atomics (small calls) or gathers them from
+    landmark-major lists built on the device (large calls); the environment variable moves the switch point so
+    that every case runs through both."""
+    monkeypatch.setenv("VO_BA_GATHER_MIN_OBS", "0" if request.param == "gather" else "1000000000")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["ba_small", "ba_mid", "ba_frozen8"])
-def test_ba_matches_golden_and_oracle(oracle, ctx, name):
+def test_ba_matches_golden_and_oracle(oracle, ctx, name, landmark_path):
     from visual_odometry_amd import hip
     d = np.load(os.path.join(GOLD, name + ".npz"))
     F, P, ci, pi = int(d["F"]), int(d["P"]), d["ci"], d["pi"]
@@ -90,7 +99,7 @@ def test_ba_matches_golden_and_oracle(oracle, ctx, name):
     assert (ne["Hcp"][:start] == 0).all()
 
 
-def test_ba_config4_shape(oracle, ctx):
+def test_ba_config4_shape(oracle, ctx, landmark_path):
     """10 keyframes x 5000 landmarks, all visible (50 000 observations), 3 frozen cameras."""
     from visual_odometry_amd import hip
     pb = synth.ba_problem(F=10, P=5000, seed=0)
@@ -112,7 +121,7 @@ def test_ba_config4_shape(oracle, ctx):
         assert np.abs(ne2[k] - ref2[k]).max() <= 1e-10 * np.abs(ref2[k]).max(), k
 
 
-def test_ba_device_and_edge_cases(oracle, ctx):
+def test_ba_device_and_edge_cases(oracle, ctx, landmark_path):
     import torch
     from visual_odometry_amd import hip
     pb = synth.ba_problem(F=4, P=100, visibility=0.6, seed=3)
@@ -142,3 +151,27 @@ def test_ba_device_and_edge_cases(oracle, ctx):
     r, _ = hip.ba_residual(ctx, tx, F, P, tb, tpi, tobs, pb["K"])
     ctx.sync()
     assert torch.isnan(r[10]).item() and torch.isfinite(r[12]).item()
+
+
+def test_ba_many_windows_default_switch(oracle, ctx):
+    """Four windows of the 10 x 5000 shape in one call (200 000 observations): above the library's own switch point,
+    so the landmark blocks come from the gather path without any override; device buffers; twice the same bits."""
+    import torch
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=10, P=5000, seed=0)
+    F, P, Wn = pb["F"], pb["P"], 4
+    cams = np.hstack([pb["x"][:6 * F] + 1e-3 * w for w in range(Wn)])
+    x = np.hstack([cams, np.tile(pb["x"][6 * F:], Wn)])
+    ci = np.hstack([pb["ci"] + F * w for w in range(Wn)])
+    pi = np.hstack([pb["pi"] + P * w for w in range(Wn)])
+    obs = np.tile(pb["obs"], (Wn, 1)).astype(np.float64)
+    assert ci.size == 200000
+    ref = oracle.ba_normal_eq(x, F * Wn, P * Wn, ci, pi, obs, pb["K"], 0)
+    t = [torch.from_numpy(a).cuda() for a in (x, ci, pi, obs)]
+    ne = hip.ba_normal_eq(ctx, t[0], F * Wn, P * Wn, t[1], t[2], t[3], pb["K"], 0)
+    ne2 = hip.ba_normal_eq(ctx, t[0], F * Wn, P * Wn, t[1], t[2], t[3], pb["K"], 0)
+    ctx.sync()
+    for k in ("Hcc", "Hpp", "Hcp", "g", "r"):
+        got = ne[k].cpu().numpy()
+        assert np.abs(got - ref[k]).max() <= 1e-10 * np.abs(ref[k]).max(), k
+    assert torch.equal(ne["Hpp"], ne2["Hpp"]) and torch.equal(ne["g"][6 * F * Wn:], ne2["g"][6 * F * Wn:])   # ordered sums

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
                                                         double *__restrict__ r, double *__restrict__ cost,
                                                         double *__restrict__ Hcc, double *__restrict__ Hpp,
                                                         double *__restrict__ Hcp, double *__restrict__ g,
-                                                        double *__restrict__ cam_rep, double *__restrict__ Jp_out = nullptr)
+                                                        double *__restrict__ cam_rep, double *__restrict__ Jp_out = nullptr,
+                                                        const int *__restrict__ list_start = nullptr,
+                                                        const int *__restrict__ list_slot = nullptr, int *__restrict__ list_obs = nullptr)
 {
     const int i = blockIdx.x * BA_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
         if (valid) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) Jp_out[6 * (int64_t)i + a] = Jp[a];
+            // landmark-major observation lists built on the device: this observation's place in its landmark's list
+            if (list_obs && ok) list_obs[list_start[p] + list_slot[i]] = i;
         }
     } else if (active) {  // point blocks: per-lane atomics
         // upper triangle only; ba_cam_sum_kernel mirrors it afterwards
@@ -279,6 +283,117 @@ __global__ __launch_bounds__(256) void ba_cam_sum_kernel(int F, const double *__
     const int c = t / 42, e = t - 42 * c;
     if (e < 36) Hcc[36 * (int64_t)c + e] = s;
     else g[6 * (int64_t)c + (e - 36)] = s;
+}
+
+// ---- landmark-major observation lists built on the device (large calls of vo_ba_normal_eq) -------------
+// slot[i] = how many observations of landmark pi[i] were counted before this one (any order: integer atomics);
+// cnt[p] = observations of landmark p.  Out-of-range indices get slot -1 and are left out.
+__global__ __launch_bounds__(256) void ba_list_count_kernel(const int64_t *__restrict__ ci, const int64_t *__restrict__ pi, int O, int F,
+                                                           int P, int *__restrict__ cnt, int *__restrict__ slot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= O) return;
+    const int64_t c = ci[i], p = pi[i];
+    slot[i] = (c >= 0 && c < F && p >= 0 && p < P) ? atomicAdd(cnt + p, 1) : -1;
+}
+
+#define BA_SCAN 1024
+__device__ __forceinline__ int ba_block_scan(int v, int &total)       // inclusive scan over the workgroup
+{
+    __shared__ int part[BA_SCAN];
+    __syncthreads();
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < BA_SCAN; d <<= 1) {
+        const int add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    total = part[BA_SCAN - 1];
+    return part[threadIdx.x];
+}
+
+__global__ __launch_bounds__(BA_SCAN) void ba_scan_sums_kernel(const int *__restrict__ cnt, int P, int *__restrict__ bsum)
+{
+    const int i = blockIdx.x * BA_SCAN + threadIdx.x;
+    int total;
+    ba_block_scan(i < P ? cnt[i] : 0, total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(BA_SCAN) void ba_scan_offsets_kernel(int *__restrict__ bsum, int nblk)      // exclusive, in place
+{
+    int carry = 0;
+    for (int base = 0; base < nblk; base += BA_SCAN) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? bsum[i] : 0;
+        int total;
+        const int inc = ba_block_scan(v, total);
+        if (i < nblk) bsum[i] = carry + inc - v;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(BA_SCAN) void ba_scan_finish_kernel(const int *__restrict__ cnt, int P, const int *__restrict__ boff,
+                                                                 int *__restrict__ start)
+{
+    const int i = blockIdx.x * BA_SCAN + threadIdx.x;
+    const int v = i < P ? cnt[i] : 0;
+    int total;
+    const int inc = ba_block_scan(v, total);
+    if (i < P) start[i] = boff[blockIdx.x] + inc - v;
+    if (i == P - 1) start[P] = boff[blockIdx.x] + inc;
+}
+
+// Hpp[p], g_p from the landmark's observation list.  The list's order is the order in which the counting
+// atomics happened to land; lists of up to 64 entries are walked in ascending observation index instead
+// (repeated minimum search over the cached list), so that the float64 sums come out the same in every run.
+__global__ __launch_bounds__(256) void ba_point_gather_ordered_kernel(int P, int F, const int *__restrict__ start,
+                                                                      const int *__restrict__ list, const double *__restrict__ Jp,
+                                                                      const double *__restrict__ r, int obs_start,
+                                                                      double *__restrict__ Hpp, double *__restrict__ g)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+    const int o0 = start[p], k = start[p + 1] - o0;
+    int last = -1;
+    for (int t = 0; t < k; ++t) {
+        int i;
+        if (k <= 64) {
+            i = 0x7fffffff;
+            for (int u = 0; u < k; ++u) {
+                const int c = list[o0 + u];
+                if (c > last && c < i) i = c;
+            }
+            last = i;
+        } else {
+            i = list[o0 + t];
+        }
+        if (i < obs_start) continue;                      // frozen cameras: no Jacobian rows
+        const double *j = Jp + 6 * (int64_t)i;
+        const double j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3], j4 = j[4], j5 = j[5];
+        const double r0 = r[2 * (int64_t)i], r1 = r[2 * (int64_t)i + 1];
+        h[0] += j0 * j0 + j3 * j3; h[1] += j0 * j1 + j3 * j4; h[2] += j0 * j2 + j3 * j5;
+        h[3] += j1 * j1 + j4 * j4; h[4] += j1 * j2 + j4 * j5; h[5] += j2 * j2 + j5 * j5;
+        gp[0] += j0 * r0 + j3 * r1; gp[1] += j1 * r0 + j4 * r1; gp[2] += j2 * r0 + j5 * r1;
+    }
+    double *hp = Hpp + 9 * (int64_t)p;
+    hp[0] = h[0]; hp[1] = h[1]; hp[2] = h[2];
+    hp[3] = h[1]; hp[4] = h[3]; hp[5] = h[4];
+    hp[6] = h[2]; hp[7] = h[4]; hp[8] = h[5];
+    double *gq = g + 6 * (int64_t)F + 3 * (int64_t)p;
+    gq[0] = gp[0]; gq[1] = gp[1]; gq[2] = gp[2];
+}
+
+// From this many observations on, vo_ba_normal_eq builds landmark-major lists and gathers the landmark blocks;
+// below it the nine float64 atomics per observation are cheaper than the five extra launches.
+#define BA_GATHER_MIN_OBS 150000
+static int ba_gather_min_obs()
+{
+    const char *e = getenv("VO_BA_GATHER_MIN_OBS");       // comparison runs and tests
+    return e ? atoi(e) : BA_GATHER_MIN_OBS;
 }
 
 template <bool WITH_J>
@@ -328,15 +443,43 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
     }
     VO_HIP_CHECK(hipMemsetAsync(d_cost, 0, 8, ctx->stream));
     double *d_rep = nullptr;
+    const bool gather = WITH_J && O >= ba_gather_min_obs() && P > 0;
     if (WITH_J) {
         void *rp;
         const size_t rep_bytes = (size_t)BA_REPLICAS * (F ? F : 1) * 42 * 8;
         if ((rc = vo_stage_reserve(ctx, 1, rep_bytes, &rp))) return rc;
         d_rep = (double *)rp;
         VO_HIP_CHECK(hipMemsetAsync(d_rep, 0, rep_bytes, ctx->stream));
-        if (P) VO_HIP_CHECK(hipMemsetAsync(d_Hpp, 0, (size_t)P * 72, ctx->stream));
-        if (P) VO_HIP_CHECK(hipMemsetAsync(d_g + 6 * (size_t)F, 0, (size_t)P * 24, ctx->stream));
+        if (!gather) {
+            if (P) VO_HIP_CHECK(hipMemsetAsync(d_Hpp, 0, (size_t)P * 72, ctx->stream));
+            if (P) VO_HIP_CHECK(hipMemsetAsync(d_g + 6 * (size_t)F, 0, (size_t)P * 24, ctx->stream));
+        }
     }
+    if (gather) {
+        // work block (context slot 2): point Jacobians | slot | list | cnt | start | block sums
+        const int nblk = (P + BA_SCAN - 1) / BA_SCAN;
+        size_t off[7], tot = 0;
+        const size_t sz[6] = {(size_t)O * 48, (size_t)O * 4, (size_t)O * 4, (size_t)P * 4, ((size_t)P + 1) * 4, (size_t)nblk * 4};
+        for (int k = 0; k < 6; ++k) { off[k] = tot; tot += (sz[k] + 255) / 256 * 256; }
+        void *wp;
+        if ((rc = vo_stage_reserve(ctx, 2, tot, &wp))) return rc;
+        char *b = (char *)wp;
+        double *d_Jp = (double *)(b + off[0]);
+        int *d_slot = (int *)(b + off[1]), *d_list = (int *)(b + off[2]), *d_cnt = (int *)(b + off[3]), *d_start = (int *)(b + off[4]),
+            *d_bsum = (int *)(b + off[5]);
+        VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, (size_t)P * 4, ctx->stream));
+        hipLaunchKernelGGL(ba_list_count_kernel, dim3((O + 255) / 256), dim3(256), 0, ctx->stream, d_ci, d_pi, O, F, P, d_cnt, d_slot);
+        hipLaunchKernelGGL(ba_scan_sums_kernel, dim3(nblk), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_cnt, P, d_bsum);
+        hipLaunchKernelGGL(ba_scan_offsets_kernel, dim3(1), dim3(BA_SCAN), 0, ctx->stream, d_bsum, nblk);
+        hipLaunchKernelGGL(ba_scan_finish_kernel, dim3(nblk), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_cnt, P, (const int *)d_bsum, d_start);
+        const unsigned blocks = (unsigned)((O + BA_THREADS - 1) / BA_THREADS);
+        hipLaunchKernelGGL((ba_kernel<WITH_J, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, d_params, F, P, d_ci, d_pi, d_obs, O, Kv,
+                           obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep, d_Jp, (const int *)d_start, (const int *)d_slot, d_list);
+        hipLaunchKernelGGL(ba_point_gather_ordered_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, P, F, (const int *)d_start,
+                           (const int *)d_list, (const double *)d_Jp, (const double *)d_r, obs_start, d_Hpp, d_g);
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((F * 42 + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, 0, (double *)nullptr);
+        VO_HIP_CHECK(hipGetLastError());
+    } else {
     if (O) {
         const unsigned blocks = (unsigned)((O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL(ba_kernel<WITH_J>, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, d_params, F, P, d_ci, d_pi,
@@ -347,6 +490,7 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
         const int work = F * 42 > P ? F * 42 : P;
         hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, P, d_Hpp);
         VO_HIP_CHECK(hipGetLastError());
+    }
     }
     if (mem == VO_MEM_HOST) {
         if (O) VO_HIP_CHECK(hipMemcpyAsync(r, d_r, (size_t)O * 16, hipMemcpyDeviceToHost, ctx->stream));
