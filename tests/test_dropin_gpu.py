@@ -52,8 +52,8 @@ def test_harris_dropin(ctx):
     corners = np.array([(30, 20), (69, 20), (30, 49), (69, 49)], np.float32)
     for cx in corners:
         assert np.abs(c - cx).sum(1).min() <= 2
-    with pytest.raises(NotImplementedError):
-        FeatureExtractor(ExtractorType.SIFT).get_kp(img)
+    kps, des = FeatureExtractor(ExtractorType.SIFT).get_kp(img)          # the rectangle's corners are SIFT keypoints too
+    assert des.shape == (len(kps), 128) and all(hasattr(k, "pt") for k in kps)
 
 
 def test_pnp_recovers_planted_pose(ctx):

@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--dataset-params", default="PARKING")
+    ap.add_argument("--bootstrap", default="sift", choices=["sift", "klt"],
+                    help="correspondences of the two-view bootstraps: SIFT + matching (the reference's route) or corners + KLT")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
     if a.v:
@@ -129,7 +131,7 @@ def main():
     data = loadData.synthetic_parking(a.frames, a.seed)
     frames = list(data.frames)                   # rendering is not part of the timed loop
     data.frames = iter(frames)
-    vo = ContinuousVO(data, rescale_bootstrap=True)   # one world scale across keyframes, so the path compares with ground truth
+    vo = ContinuousVO(data, rescale_bootstrap=True, bootstrap_correspondences=a.bootstrap)   # one world scale across keyframes, so the path compares with ground truth
     calls = []
     if a.cpu_baseline:
         from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation
@@ -162,7 +164,7 @@ def main():
     if a.cpu_baseline and calls:
         step = max(1, len(calls) // a.cpu_baseline)
         out_cpu = {"cpu_baseline": cpu_frame_baseline(calls[::step][:a.cpu_baseline], np.asarray(data.K, np.float64))}
-    print(json.dumps({"frames": len(per_frame), "keyframes": [k.idx for k in vo.keyframes],
+    print(json.dumps({"frames": len(per_frame), "bootstrap": a.bootstrap, "keyframes": [k.idx for k in vo.keyframes],
                       "loop_frames_per_s": float(len(tracked) / tracked.sum()),
                       "median_ms_per_tracked_frame": float(np.median(tracked) * 1e3),
                       "bootstrap_ms": float(per_frame[vo.frames_to_skip] * 1e3),

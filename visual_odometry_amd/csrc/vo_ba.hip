@@ -663,6 +663,25 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
     }
 }
 
+// Device pointers; launches the refit and enqueues the copy of {pose (6), cost, iterations} into host_out.
+// The caller synchronises the stream before reading host_out (context slot 3 holds the device copy).
+int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const uint8_t *dmask, const double *K,
+                         const double *pose_in, int max_iters, double *host_out)
+{
+    BaK Kv;
+    memcpy(Kv.k, K, sizeof(Kv.k));
+    Pose6 start;
+    memcpy(start.v, pose_in, sizeof(start.v));
+    int rc;
+    void *p;
+    if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
+    double *d_out = (double *)p;
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out);
+    VO_HIP_CHECK(hipGetLastError());
+    VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return VO_OK;
+}
+
 extern "C" int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n, const uint8_t *mask, const double *K,
                               const double *pose_in, int max_iters, double *pose_out, double *cost_out, int mem)
 {
@@ -671,10 +690,6 @@ extern "C" int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n
     VO_REQUIRE(n == 0 || (X && x), "vo_refine_pose: NULL point buffers");
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_refine_pose: bad mem flag %d", mem);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
-    BaK Kv;
-    memcpy(Kv.k, K, sizeof(Kv.k));
-    Pose6 start;
-    memcpy(start.v, pose_in, sizeof(start.v));
     const float *dX = X, *dx = x;
     const uint8_t *dm = mask;
     int rc;
@@ -689,12 +704,8 @@ extern "C" int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n
             VO_HIP_CHECK(hipMemcpyAsync((void *)dm, mask, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         }
     }
-    if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
-    double *d_out = (double *)p;
-    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dm, n, Kv, start, max_iters, d_out);
-    VO_HIP_CHECK(hipGetLastError());
     double h[8];
-    VO_HIP_CHECK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = vo_refine_pose_async(ctx, dX, dx, n, dm, K, pose_in, max_iters, h))) return rc;
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(pose_out, h, 6 * sizeof(double));
     if (cost_out) *cost_out = h[6];

@@ -75,6 +75,7 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->stage)
         if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -125,5 +126,27 @@ int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out)
         b.cap = cap;
     }
     *out = b.ptr;
+    return VO_OK;
+}
+
+int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes < 4096) bytes = 4096;
+    if (ctx->pinned_cap < bytes) {
+        if (ctx->pinned) {
+            VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // an enqueued copy may still target the old buffer
+            VO_HIP_CHECK(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_cap = 0;
+        }
+        const size_t cap = bytes + bytes / 2;
+        hipError_t e = hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            vo_set_error("page-locked host allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
+            return VO_ENOMEM;
+        }
+        ctx->pinned_cap = cap;
+    }
+    *out = ctx->pinned;
     return VO_OK;
 }

@@ -39,12 +39,17 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vo_devbuf stage[8];
+    void *pinned = nullptr;      // page-locked host buffer for small read-backs (a copy into pageable memory blocks the caller)
+    size_t pinned_cap = 0;
 };
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
 
 // Looks up the current device's copy of the fixed scratch array of vo_klt_track_fb_noalloc (vo_klt.hip).
 int vo_klt_noalloc_setup(int device);
+
+// Page-locked host scratch of at least `bytes` (contents survive until the next call that asks for more).
+int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out);
 
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);

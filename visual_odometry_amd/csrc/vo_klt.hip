@@ -848,10 +848,18 @@ extern "C" int vo_klt_track(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
     a.prev_pts = (const float *)d_in; a.init_pts = (const float *)d_init; a.next_pts = (float *)d_out;
     a.status = (uint8_t *)d_st; a.err = (float *)d_err;
     if ((rc = launch_klt(ctx, a))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(next_pts, d_out, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(status, d_st, cnt, hipMemcpyDeviceToHost, ctx->stream));
-    if (err) VO_HIP_CHECK(hipMemcpyAsync(err, d_err, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // results come back through page-locked memory: three copies in flight, one wait (a copy into pageable memory
+    // blocks the caller until it has landed)
+    void *pin;
+    if ((rc = vo_pinned_reserve(ctx, cnt * 13 + 64, &pin))) return rc;
+    char *hp = (char *)pin;
+    VO_HIP_CHECK(hipMemcpyAsync(hp, d_out, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (err) VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 8, d_err, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 12, d_st, cnt, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(next_pts, hp, cnt * 8);
+    if (err) memcpy(err, hp + cnt * 8, cnt * 4);
+    memcpy(status, hp + cnt * 12, cnt);
     return VO_OK;
 }
 
@@ -910,9 +918,14 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
                        (uint8_t *)d_mask, (int64_t)cnt);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(next_pts, d_fwd, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(mask, d_mask, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        void *pin;
+        if ((rc = vo_pinned_reserve(ctx, cnt * 9 + 64, &pin))) return rc;
+        char *hp = (char *)pin;
+        VO_HIP_CHECK(hipMemcpyAsync(hp, d_fwd, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 8, d_mask, cnt, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(next_pts, hp, cnt * 8);
+        memcpy(mask, hp + cnt * 8, cnt);
     }
     return VO_OK;
 }

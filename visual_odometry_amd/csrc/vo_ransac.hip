@@ -63,12 +63,13 @@ extern "C" int vo_ransac_draw_subsets(uint64_t *rng_state, int count, int model_
 
 // ---------------------------------------------------------------------------
 // Whole RANSAC calls.  One entry point stands in for one cv2 call: all samples are
-// drawn up front (above), the GPU solves every minimal problem and scores every
-// candidate against every correspondence (two launches, candidates and points stay
-// on the device), the host reads back one inlier count per candidate and replays
-// OpenCV's sequential loop over them -- best-so-far update, adaptive iteration
-// count, early stop -- so the outcome equals that loop run on the same candidate
-// sequence; a third launch produces the winner's inlier mask.
+// drawn as OpenCV draws them, in chunks (256, 1024, then 4096 at a time); per chunk the
+// GPU solves every minimal problem and scores every candidate against every
+// correspondence (two launches, candidates and points stay on the device), the host
+// reads back one inlier count per candidate and replays OpenCV's sequential loop over
+// them -- best-so-far update, adaptive iteration count, early stop -- so the outcome
+// equals that loop run on the same candidate sequence, and no chunk is solved past the
+// iteration at which the loop ends; a last launch produces the winner's inlier mask.
 // ---------------------------------------------------------------------------
 
 // RANSACUpdateNumIters: iterations needed for confidence p at outlier ratio ep
@@ -84,25 +85,39 @@ static int ransac_update_num_iters(double p, double ep, int model_points, int ma
     return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)lrint(num / denom);
 }
 
-// counts: per_sample candidates per iteration (unused slots flagged by used[] == 0).  Returns the winning
-// candidate index or -1.
-static int replay_ransac_loop(const int32_t *counts, const uint8_t *used, int per_sample, int n, int model_points,
-                              double conf, int max_iters)
-{
-    int niters = max_iters, best = -1, best_c = -1;
-    for (int it = 0; it < niters; ++it)
-        for (int s = 0; s < per_sample; ++s) {
-            const int c = it * per_sample + s;
-            if (!used[c]) continue;
-            const int good = counts[c];
-            if (good > (best > model_points - 1 ? best : model_points - 1)) {
-                best = good;
-                best_c = c;
-                niters = ransac_update_num_iters(conf, (double)(n - good) / n, model_points, niters);
+// OpenCV's sequential loop, replayed over candidates that were solved and scored chunk by chunk.
+struct RansacReplay {
+    int niters, best = -1, best_c = -1, done = 0;    // done: iterations replayed so far
+    explicit RansacReplay(int max_iters) : niters(max_iters) {}
+    bool finished() const { return done >= niters; }
+    // counts / used: the candidates of iterations [first, first + count), per_sample slots each (used == 0: no such
+    // solution); candidate ids are global (iteration * per_sample + slot)
+    void feed(const int32_t *counts, const uint8_t *used, int per_sample, int first, int count, int n, int model_points,
+              double conf)
+    {
+        for (int it = first; it < first + count && it < niters; ++it) {
+            for (int s = 0; s < per_sample; ++s) {
+                const int c = (it - first) * per_sample + s;
+                if (!used[c]) continue;
+                const int good = counts[c];
+                if (good > (best > model_points - 1 ? best : model_points - 1)) {
+                    best = good;
+                    best_c = it * per_sample + s;
+                    niters = ransac_update_num_iters(conf, (double)(n - good) / n, model_points, niters);
+                }
             }
+            done = it + 1;
         }
-    return best_c;
-}
+    }
+};
+
+// Samples are solved and scored in chunks: 256 first, then four times as many each round (clean data stop the
+// adaptive loop after a handful of iterations; the reference's parking parameters allow 10 000).
+static int ransac_chunk(int round) { return round == 0 ? 256 : round == 1 ? 1024 : 4096; }
+
+// vo_ba.hip: launches the refit and enqueues the copy of {pose (6), cost, iterations} into host_out; no synchronisation
+int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const uint8_t *dmask, const double *K,
+                         const double *pose_in, int max_iters, double *host_out);
 
 static void rotvec_from_matrix(const double *R, double *rv)
 {
@@ -149,16 +164,22 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     if (n < 4) return VO_OK;
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const int S = max_iters;
-    int rc;
+    int rc = VO_OK;
     void *p;
-    uint64_t state = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    uint64_t state = state0;
     std::unique_ptr<int32_t[]> subsets_buf(new (std::nothrow) int32_t[(size_t)S * 4]);
-    std::unique_ptr<int32_t[]> counts_buf(new (std::nothrow) int32_t[(size_t)S * 2]);     // S counts, then S validity flags (bytes)
-    if (!subsets_buf || !counts_buf) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
-    int32_t *subsets = subsets_buf.get(), *counts = counts_buf.get();
-    uint8_t *valid = (uint8_t *)(counts + S);
-    if ((rc = vo_ransac_draw_subsets(&state, n, 4, S, nullptr, nullptr, 1, subsets))) return rc;
-    if (rng_state) *rng_state = state;
+    if (!subsets_buf) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
+    // page-locked read-back area: a chunk's counts (4096 ints), validity flags (4096 bytes in 4096 ints), candidate
+    // poses (4096 x 12 doubles), then the inlier mask (n bytes) and the refit's 8 doubles
+    void *pin;
+    if ((rc = vo_pinned_reserve(ctx, (size_t)4096 * 8 + (size_t)4096 * 96 + 64 + (size_t)n + 64, &pin))) return rc;
+    int32_t *counts = (int32_t *)pin;
+    double *poses = (double *)((char *)pin + (size_t)4096 * 8);
+    double *refined = poses + (size_t)4096 * 12;
+    uint8_t *pin_mask = (uint8_t *)(refined + 8);
+    double Rt[12] = {0};
+    int32_t *subsets = subsets_buf.get();
     const float *dX = X, *dx = x;
     uint8_t *dmask = inlier_mask;
     // staging slots 0, 1 (points), 2 (subsets), 4 (candidates), 5 (counts + flags), 6 (mask); slot 3 belongs to vo_refine_pose
@@ -176,32 +197,54 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     if ((rc = vo_stage_reserve(ctx, 5, (size_t)S * 5 + 16, &p))) return rc;
     int32_t *dcounts = (int32_t *)p;
     uint8_t *dvalid = (uint8_t *)(dcounts + S);
-    VO_HIP_CHECK(hipMemcpyAsync(dsub, subsets, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub, S, dRt, dvalid, VO_MEM_DEVICE))) return rc;
-    if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt, S, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts, (size_t)S * 5, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int win = replay_ransac_loop(counts, valid, 1, n, 4, conf, max_iters);
+    RansacReplay loop(max_iters);
+    for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
+        const int c = ransac_chunk(round) < S - first ? ransac_chunk(round) : S - first;
+        if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, subsets + (size_t)first * 4))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 4, subsets + (size_t)first * 4, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub + (size_t)first * 4, c, dRt + (size_t)first * 12, dvalid + first, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)first * 12, c, thr, dcounts + first, nullptr, VO_MEM_DEVICE))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts + first, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(counts + 4096, dvalid + first, (size_t)c, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(poses, dRt + (size_t)first * 12, (size_t)c * 96, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int before = loop.best_c;
+        loop.feed(counts, (const uint8_t *)(counts + 4096), 1, first, c, n, 4, conf);
+        if (loop.best_c != before) memcpy(Rt, poses + (size_t)(loop.best_c - first) * 12, sizeof(Rt));
+        first += c;
+    }
+    if (rng_state) {     // the generator after the iterations the loop ran, as OpenCV's own loop leaves it
+        const int ran = loop.niters < S ? loop.niters : S;
+        uint64_t st = state0;
+        std::unique_ptr<int32_t[]> scratch(new (std::nothrow) int32_t[(size_t)(ran > 0 ? ran : 1) * 4]);
+        if (!scratch) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
+        if (ran > 0 && (rc = vo_ransac_draw_subsets(&st, n, 4, ran, nullptr, nullptr, 1, scratch.get()))) return rc;
+        *rng_state = st;
+    }
+    const int win = loop.best_c;
     if (win < 0) return VO_OK;
-    double Rt[12];
-    int32_t good = 0;
+    // winner's mask and the refit on its inliers back to back: the inlier count is already known from the loop
+    const int32_t good = loop.best;
     if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)win * 12, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(Rt, dRt + (size_t)win * 12, sizeof(Rt), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(&good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipMemcpyAsync(inlier_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (good >= 4 && refine_iters > 0) {
-        // refit on the inliers (OpenCV refits with EPnP there; here Gauss-Newton on the same error)
-        double R[9], pose[6], out[6], cost;
+    const bool refit = good >= 4 && refine_iters > 0;
+    if (refit) {
+        // OpenCV refits with EPnP there; here Gauss-Newton on the same error
+        double R[9], pose[6];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = Rt[4 * r + c];
         rotvec_from_matrix(R, pose);
         pose[3] = Rt[3]; pose[4] = Rt[7]; pose[5] = Rt[11];
-        if ((rc = vo_refine_pose(ctx, dX, dx, n, dmask, K, pose, refine_iters, out, &cost, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_refine_pose_async(ctx, dX, dx, n, dmask, K, pose, refine_iters, refined))) return rc;
+    }
+    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipMemcpyAsync(pin_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mem == VO_MEM_HOST) memcpy(inlier_mask, pin_mask, (size_t)n);
+    if (refit) {
         bool finite = true;
-        for (int k = 0; k < 6; ++k) finite = finite && isfinite(out[k]);
+        for (int k = 0; k < 6; ++k) finite = finite && isfinite(refined[k]);
         if (finite) {
-            matrix_from_rotvec(out, R);
-            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[4 * r + c] = R[3 * r + c]; Rt[4 * r + 3] = out[3 + r]; }
+            double R[9];
+            matrix_from_rotvec(refined, R);
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[4 * r + c] = R[3 * r + c]; Rt[4 * r + 3] = refined[3 + r]; }
         }
     }
     memcpy(Rt_out, Rt, sizeof(Rt));
@@ -220,16 +263,20 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     if (n < 8) return VO_OK;   // OpenCV needs >= 7 and switches estimators below 15; the RANSAC form is kept for n >= 8
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const int S = max_iters;
-    int rc;
+    int rc = VO_OK;
     void *p;
-    uint64_t state = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    uint64_t state = state0;
     std::unique_ptr<int32_t[]> subsets_buf(new (std::nothrow) int32_t[(size_t)S * 7]);
-    std::unique_ptr<int32_t[]> counts_buf(new (std::nothrow) int32_t[(size_t)S * 5]);     // 3S counts, S solution counts, 3S flags (bytes)
-    if (!subsets_buf || !counts_buf) { vo_set_error("vo_find_fundamental_ransac: out of host memory"); return VO_ENOMEM; }
-    int32_t *subsets = subsets_buf.get(), *counts = counts_buf.get();
-    // the collinearity test of the sampler reads the points on the host
-    if ((rc = vo_ransac_draw_subsets(&state, n, 7, S, m1, m2, 10000, subsets))) return rc;
-    if (rng_state) *rng_state = state;
+    if (!subsets_buf) { vo_set_error("vo_find_fundamental_ransac: out of host memory"); return VO_ENOMEM; }
+    // page-locked read-back area: a chunk's 3c counts and c solution counts (contiguous on the device too), room for the
+    // 3c validity flags formed here, then the winner: F (9 doubles), its count, the inlier mask (n bytes)
+    void *pin;
+    if ((rc = vo_pinned_reserve(ctx, (size_t)4096 * 20 + 128 + (size_t)n + 64, &pin))) return rc;
+    int32_t *subsets = subsets_buf.get(), *counts = (int32_t *)pin;
+    double *pin_F = (double *)((char *)pin + (size_t)4096 * 20);
+    int32_t *pin_good = (int32_t *)(pin_F + 9);
+    uint8_t *pin_mask = (uint8_t *)(pin_F + 12);
     if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 8, &p))) return rc;
     float *d1 = (float *)p;
     if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc;
@@ -244,23 +291,41 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     uint8_t *dmask = (uint8_t *)p;
     VO_HIP_CHECK(hipMemcpyAsync(d1, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP_CHECK(hipMemcpyAsync(d2, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(dsub, subsets, (size_t)S * 28, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub, S, dF, dnsol, VO_MEM_DEVICE))) return rc;
-    if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF, 3 * S, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts, (size_t)S * 16, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int32_t *nsol = counts + 3 * (size_t)S;
-    uint8_t *used = (uint8_t *)(counts + 4 * (size_t)S);
-    for (int s = 0; s < S; ++s)
-        for (int k = 0; k < 3; ++k) used[3 * s + k] = k < nsol[s];
-    const int win = replay_ransac_loop(counts, used, 3, n, 7, conf, max_iters);
+    RansacReplay loop(max_iters);
+    for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
+        const int c = ransac_chunk(round) < S - first ? ransac_chunk(round) : S - first;
+        // the collinearity test of the sampler reads the points on the host
+        if ((rc = vo_ransac_draw_subsets(&state, n, 7, c, m1, m2, 10000, subsets + (size_t)first * 7))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub + (size_t)first * 7, c, dF + (size_t)first * 27, dnsol + first, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)first * 27, 3 * c, thr, dcounts + 3 * (size_t)first, nullptr, VO_MEM_DEVICE))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts + 3 * (size_t)first, (size_t)c * 12, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(counts + 3 * 4096, dnsol + first, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int32_t *nsol = counts + 3 * 4096;
+        uint8_t *used = (uint8_t *)(counts + 4 * 4096);
+        for (int q = 0; q < c; ++q)
+            for (int k = 0; k < 3; ++k) used[3 * q + k] = k < nsol[q];
+        loop.feed(counts, used, 3, first, c, n, 7, conf);
+        first += c;
+    }
+    if (rng_state) {     // the generator after the iterations the loop ran, as OpenCV's own loop leaves it
+        const int ran = loop.niters < S ? loop.niters : S;
+        uint64_t st = state0;
+        std::unique_ptr<int32_t[]> scratch(new (std::nothrow) int32_t[(size_t)(ran > 0 ? ran : 1) * 7]);
+        if (!scratch) { vo_set_error("vo_find_fundamental_ransac: out of host memory"); return VO_ENOMEM; }
+        if (ran > 0 && (rc = vo_ransac_draw_subsets(&st, n, 7, ran, m1, m2, 10000, scratch.get()))) return rc;
+        *rng_state = st;
+    }
+    const int win = loop.best_c;
     if (win < 0) return VO_OK;
-    int32_t good = 0;
     if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)win * 9, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(F_out, dF + (size_t)win * 9, 72, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(&good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(inlier_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(pin_F, dF + (size_t)win * 9, 72, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(pin_good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(pin_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *n_inliers = good;
+    memcpy(F_out, pin_F, 72);
+    memcpy(inlier_mask, pin_mask, (size_t)n);
+    *n_inliers = *pin_good;
     return VO_OK;
 }
