@@ -189,6 +189,61 @@ def main():
         out.append(rec)
         del a, b
 
+    # ---- FeatureExtractor.harris tail: connected components, the fused corner call -----------------------------
+    img = synth.frame_pair(synth.KITTI_SHAPE, seed=2021)[0]
+    timg = torch.from_numpy(img).to(dev)
+    tmask = hip.harris_mask(ctx, timg, 0.1, 0.01)
+    mask_h = tmask.cpu().numpy()
+    n_lab = hip.connected_components(ctx, tmask, 1)[0]
+    ms = timed(ctx, lambda: hip.connected_components(ctx, tmask, 1))
+    px = img.size
+    out.append({"op": "connected_components", "workload": f"1241x376 Harris mask, {100 * (mask_h != 0).mean():.0f} % foreground, {n_lab} labels, "
+                "labels + areas + centroids, first-2x2-block numbering; host wall time incl. the count read-back", "ms": ms,
+                "algorithmic_bytes": px * 5 + n_lab * 20, "roofline": {"bound": "hbm", "achieved": (px * 5 + n_lab * 20) / (ms * 1e-3) / 1e9,
+                                                                       "peak": HBM, "unit": "GB/s", "frac": (px * 5 + n_lab * 20) / (ms * 1e-3) / 1e9 / HBM},
+                "cpu_oracle_ms": cpu_time(lambda: oracle.connected_components(mask_h, 1)), "cpu_cores": 1})
+    ms = timed(ctx, lambda: hip.harris_corners(ctx, timg, max_corners=4096))
+    out.append({"op": "harris_corners (FeatureExtractor.harris in one call)", "workload": "one 1241x376 frame: response, dilation, threshold, "
+                "connected components, centroids, cornerSubPix 11x11 <= 50 rounds; device-resident image, one synchronisation", "ms": ms,
+                "corners": int(hip.harris_corners(ctx, timg, max_corners=4096).shape[0]),
+                "cpu_oracle_ms": cpu_time(lambda: oracle.harris_corners(img)), "cpu_cores": 1})
+
+    # ---- two-view cheirality vote ----------------------------------------------------------------------------
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    sc2 = synth.two_view_scene(n=3000, seed=3)
+    Kf = sc2["K"].astype(np.float32)
+    motions = BootstrapInitializer.motion_hypotheses(Kf.T @ sc2["F"] @ Kf)
+    M1 = Kf @ np.eye(3, 4, dtype=np.float32)
+    M2 = np.stack([Kf @ m for m in motions])
+    h1 = torch.from_numpy(np.hstack([sc2["m1"], np.ones((3000, 1), np.float32)]).astype(np.float32)).to(dev)
+    h2 = torch.from_numpy(np.hstack([sc2["m2"], np.ones((3000, 1), np.float32)]).astype(np.float32)).to(dev)
+    ms = timed(ctx, lambda: hip.cheirality_vote(ctx, h1, h2, M1, M2, motions))
+    from oracle import solvers_np
+    h1n, h2n = h1.cpu().numpy(), h2.cpu().numpy()
+    t0 = time.perf_counter(); solvers_np.cheirality_votes(h1n[:300], h2n[:300], M1, M2, motions); cpu = (time.perf_counter() - t0) * 10
+    out.append({"op": "cheirality_vote", "workload": "3000 pairs x 4 motion hypotheses: triangulation + in-front counts, one launch", "ms": ms,
+                "triangulations_per_s": 12000 / (ms * 1e-3), "cpu_numpy_per_point_svd_ms (the reference's loop, extrapolated from 300 pairs)": cpu * 1e3})
+
+    # ---- SIFT ----------------------------------------------------------------------------------------------------
+    for shape, name in [(synth.KITTI_SHAPE, "1241x376"), ((480, 640), "640x480")]:
+        im = synth.frame_pair(shape, seed=2021)[0]
+        tim = torch.from_numpy(im).to(dev)
+        kp, _ = hip.sift_detect_compute(ctx, tim)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hip.sift_detect_compute(ctx, tim)
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hip.sift_scale_space_image(ctx, im, 0, 0)
+        ms_space = (time.perf_counter() - t0) / 10 * 1e3
+        t0 = time.perf_counter(); oracle.sift(im); cpu = (time.perf_counter() - t0) * 1e3
+        W2, H2 = 2 * shape[1], 2 * shape[0]
+        space_bytes = int(W2 * H2 * 4 * (4.0 / 3.0) * (7 * 3 + 6 * 3))     # per Gaussian image: row pass r+w, column pass r+w... (see DESIGN)
+        out.append({"op": "sift_detect_compute", "workload": f"one {name} frame, nOctaveLayers 4, contrast 0.03, edge 10, sigma 1.6 "
+                    f"({len(kp)} keypoints); device-resident image; host wall time (keypoints are ordered on the host)", "ms": ms,
+                    "keypoints": int(len(kp)), "ms_scale_space_only (build + one image read back)": ms_space, "cpu_oracle_ms": cpu, "cpu_cores": 1})
+
     for o in out:
         print(json.dumps(o), flush=True)
 
