@@ -18,9 +18,10 @@
 //   sift_extrema_kernel      26-neighbour test over the four middle layers; candidates appended with one atomic
 //   sift_refine_kernel       one wavefront per candidate: Newton refinement (every lane, same values), orientation
 //                            histogram with lane b adding bin b's samples in raster order (deterministic float sums)
-//   sift_descriptor_kernel   one wavefront per keypoint: lanes form the samples of 64 window positions at a time,
-//                            compacted in raster order; lane c (0..35) owns spatial cell c of the 6x6x10 histogram
-//                            and adds the samples that touch it in that order
+//   sift_descriptor_kernel   four keypoints per wavefront: sixteen lanes form the samples of sixteen window positions at
+//                            a time, compacted in raster order; lane c owns inner cell c of the histogram (only the
+//                            4x4 inner cells of the 6x6x10 histogram reach the descriptor) and adds the samples that
+//                            touch it in that order
 // Sorting / de-duplication of the few thousand keypoints runs on the host between the two per-keypoint kernels.
 #include "vo_internal.h"
 #include <math.h>
@@ -47,7 +48,7 @@
 struct SiftKernel { int n; float k[SIFT_MAX_TAPS + 1]; };
 struct SiftCand { int octave, layer, r, c; };
 // descriptor job of one keypoint: image, rounded centre, rotation already divided by the histogram width
-struct SiftJob { int octave, layer, px, py, radius; float ori, cos_t, sin_t; };
+struct SiftJob { int octave, layer, px, py, radius, out; float ori, cos_t, sin_t; };     // out: descriptor row
 
 __host__ __device__ static inline int sift_floor(float v) { int i = (int)v; return i - (i > v); }
 
@@ -137,19 +138,27 @@ __global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float *__rest
     dst[(size_t)y * w + x] = acc;
 }
 
-// Column pass: a lane owns a column and walks ROWS output rows, reading the 2r + 1 rows of each through the
-// cache (neighbouring lanes read neighbouring addresses); centre tap first, then symmetric pairs.
-#define SIFT_COL_ROWS 8
+// Column pass: a workgroup stages a 64-column strip of SIFT_COL_ROWS + 2r rows in LDS (rows reflected at the image
+// border; 64 consecutive floats per row, so global reads are coalesced and LDS reads conflict-free), then every
+// lane finishes eight outputs of its column from LDS: centre tap first, then symmetric pairs.  Every input row
+// is read from memory (SIFT_COL_ROWS + 2r) / SIFT_COL_ROWS times instead of 2r + 1 times.
+#define SIFT_COL_ROWS 32
 __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                             SiftKernel K)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SIFT_COL_ROWS, r = K.n >> 1;
+    __shared__ float tile[(SIFT_COL_ROWS + SIFT_MAX_TAPS + 1) * 64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + tx, y0 = blockIdx.y * SIFT_COL_ROWS, r = K.n >> 1;
+    const int rows = min(SIFT_COL_ROWS, h - y0) + 2 * r;
+    if (x < w)
+        for (int i = ty; i < rows; i += 4) tile[i * 64 + tx] = src[(size_t)reflect101(y0 - r + i, h) * w + x];
+    __syncthreads();
     if (x >= w) return;
-    for (int y = y0; y < min(y0 + SIFT_COL_ROWS, h); ++y) {
-        float acc = K.k[r] * src[(size_t)y * w + x];
-        for (int j = 1; j <= r; ++j)
-            acc += K.k[r + j] * (src[(size_t)reflect101(y + j, h) * w + x] + src[(size_t)reflect101(y - j, h) * w + x]);
-        dst[(size_t)y * w + x] = acc;
+    for (int yy = ty; yy < SIFT_COL_ROWS && y0 + yy < h; yy += 4) {
+        const float *c = tile + (yy + r) * 64 + tx;
+        float acc = K.k[r] * c[0];
+        for (int j = 1; j <= r; ++j) acc += K.k[r + j] * (c[j * 64] + c[-j * 64]);
+        dst[(size_t)(y0 + yy) * w + x] = acc;
     }
 }
 
@@ -168,28 +177,54 @@ __global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__
     dog[plane * blockIdx.y + t] = a[plane + t] - a[t];
 }
 
+// A workgroup tests 64 x 4 pixels of one layer.  It first stages the 66 x 6 neighbourhood of the layer and of its two
+// neighbours in LDS with coalesced reads that are all in flight at once (testing straight from memory made every
+// wavefront wait for three dependent rounds of reads: 185 us at the finest octave of a 1241 x 376 frame).
 __global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restrict__ dog, size_t plane, int w, int h, int octave,
                                                           int threshold, SiftCand *__restrict__ cand, int *__restrict__ count,
                                                           int cap)
 {
-    const int c = SIFT_IMG_BORDER + blockIdx.x * 64 + (threadIdx.x & 63), r = SIFT_IMG_BORDER + blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ float t[3][6][68];
+    const int c0 = SIFT_IMG_BORDER + blockIdx.x * 64, r0 = SIFT_IMG_BORDER + blockIdx.y * 4;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = c0 + tx, r = r0 + ty;
     const int layer = 1 + blockIdx.z;
-    if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
-    const float *img = dog + plane * layer, *prev = img - plane, *next = img + plane;
-    const size_t at = (size_t)r * w + c;
-    const float val = img[at];
-    if (!(fabsf(val) > (float)threshold)) return;
-    bool is_max = val > 0, is_min = val < 0;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const size_t q = at + (size_t)((long)dy * w + dx);
-            const float a = prev[q], b = img[q], cc = next[q];
-            is_max = is_max && val >= a && val >= b && val >= cc;
-            is_min = is_min && val <= a && val <= b && val <= cc;
+    const float *planes = dog + plane * (layer - 1);
+    for (int i = threadIdx.x; i < 3 * 6 * 66; i += 256) {
+        const int pl = i / 396, rem = i - pl * 396, ry = rem / 66, rx = rem - ry * 66;
+        const int y = min(r0 - 1 + ry, h - 1), x = min(c0 - 1 + rx, w - 1);       // the border of 5 keeps y - 1, x - 1 inside
+        t[pl][ry][rx] = planes[plane * pl + (size_t)y * w + x];
+    }
+    __syncthreads();
+    bool found = false;
+    if (c < w - SIFT_IMG_BORDER && r < h - SIFT_IMG_BORDER) {
+        const float val = t[1][ty + 1][tx + 1];
+        if (fabsf(val) > (float)threshold) {
+            float hi = -__builtin_inff(), lo = __builtin_inff();
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float b = t[pl][ty + dy][tx + dx];
+                        hi = fmaxf(hi, b);
+                        lo = fminf(lo, b);
+                    }
+            found = (val > 0 && val >= hi) || (val < 0 && val <= lo);
         }
-    if (!is_max && !is_min) return;
-    const int slot = atomicAdd(count, 1);
-    if (slot < cap) cand[slot] = SiftCand{octave, layer, r, c};
+    }
+    // one atomic per wavefront
+    const unsigned long long m = __ballot(found);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (found) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) cand[slot] = SiftCand{octave, layer, r, c};
+    }
 }
 
 struct SiftOctaves {
@@ -323,30 +358,37 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict
     }
 }
 
-// One wavefront per keypoint.  LDS: 6x6 cells x 10 orientation bins; a chunk of samples (cell, 8 weights each).
-#define SIFT_DESC_CHUNK 256
+// Four keypoints per wavefront, sixteen lanes each.  Only the 4x4 inner cells of the 6x6x10 histogram reach the
+// descriptor, so a keypoint needs sixteen owners: lane l of a group owns inner cell (l / 4, l % 4) with its ten
+// orientation bins (LDS).  A group walks its keypoint's window sixteen positions at a time, keeps the samples that
+// fall inside the rotated 4x4 grid in a small buffer in raster order, and when the buffer fills every owner adds
+// the waiting samples that touch its cell, in that order -- the scalar algorithm's order of additions per bin.
+#define SIFT_DESC_BUF 64
 __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftJob *__restrict__ jobs,
                                                             int n_jobs, float *__restrict__ desc)
 {
     constexpr int d = SIFT_DESCR_WIDTH, n = SIFT_DESCR_HIST_BINS;
-    __shared__ float hist[(d + 2) * (d + 2) * (n + 2)];
-    __shared__ float s_v[SIFT_DESC_CHUNK][8];
-    __shared__ int s_cell[SIFT_DESC_CHUNK];
-    __shared__ float s_dst[d * d * n];
-    __shared__ float s_scale[2];
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= n_jobs) return;
-    const SiftJob jb = jobs[blockIdx.x];
+    __shared__ float hist[4][d * d * (n + 2)];
+    __shared__ float s_v[4][SIFT_DESC_BUF][8];
+    __shared__ int s_cell[4][SIFT_DESC_BUF];
+    __shared__ float s_dst[4][d * d * n];
+    __shared__ float s_scale[4][2];
+    const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+    const int job = blockIdx.x * 4 + g;
+    const bool has = job < n_jobs;
+    const SiftJob jb = jobs[has ? job : n_jobs - 1];
     const int w = O.w[jb.octave], h = O.h[jb.octave];
     const float *img = pool + O.gauss_off[jb.octave] + (size_t)w * h * jb.layer;
-    for (int t = lane; t < (d + 2) * (d + 2) * (n + 2); t += 64) hist[t] = 0.f;
+    for (int t = gl; t < d * d * (n + 2); t += 16) hist[g][t] = 0.f;
     const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
-    const int radius = jb.radius, side = 2 * radius + 1, len = side * side;
-    const int my_r = lane / (d + 2), my_c = lane % (d + 2);        // the cell lane < 36 owns
-    int filled = 0;                                                 // samples waiting in the chunk (wave-uniform)
-    __syncthreads();
-    for (int base = 0; base < len; base += 64) {
-        const int idx = base + lane;
+    const int radius = jb.radius, side = 2 * radius + 1, len = has ? side * side : 0;
+    const int max_len = max(max(__shfl(len, 0), __shfl(len, 16)), max(__shfl(len, 32), __shfl(len, 48)));
+    const int my_cell = ((gl >> 2) + 1) * (d + 2) + (gl & 3) + 1;      // index of this lane's cell in the 6x6 grid
+    float *mine = hist[g] + gl * (n + 2);
+    int filled = 0;                                                     // samples waiting in this group's buffer
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < max_len; base += 16) {
+        const int idx = base + gl;
         bool ok = false;
         float v[8];
         int cell = 0;
@@ -373,67 +415,74 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
                 v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
                 v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
                 v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
-                cell = ((r0 + 1) << 16) | ((c0 + 1) << 8) | o0;
+                cell = (((r0 + 1) * (d + 2) + c0 + 1) << 8) | o0;          // first of the four cells it touches, orientation bin
             }
         }
-        // compact in raster order behind the samples already waiting
-        const unsigned long long m = __ballot(ok);
+        // compact in raster order behind the samples already waiting in the group's buffer
+        const unsigned gm = (unsigned)(__ballot(ok) >> (16 * g)) & 0xffffu;
         if (ok) {
-            const int at = filled + __popcll(m & ((1ull << lane) - 1ull));
-            s_cell[at] = cell;
+            const int at = filled + __popc(gm & ((1u << gl) - 1u));
+            s_cell[g][at] = cell;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s_v[at][q] = v[q];
+            for (int q = 0; q < 8; ++q) s_v[g][at][q] = v[q];
         }
-        filled += __popcll(m);
-        if (filled > SIFT_DESC_CHUNK - 64 || base + 64 >= len) {
-            // the owner of a cell adds the waiting samples that touch it, in their (raster) order
-            __syncthreads();
-            if (lane < (d + 2) * (d + 2)) {
-                float *mine = hist + lane * (n + 2);
-                for (int sidx = 0; sidx < filled; ++sidx) {
-                    const int cl = s_cell[sidx];
-                    const int dr = my_r - (cl >> 16), dc = my_c - ((cl >> 8) & 255);
-                    if ((unsigned)dr < 2u && (unsigned)dc < 2u) {
-                        const int o0 = cl & 255, q = 4 * dr + 2 * dc;
-                        mine[o0] += s_v[sidx][q];
-                        mine[o0 + 1] += s_v[sidx][q + 1];
+        filled += __popc(gm);
+        // when one group's buffer is full (or its window ends) all four groups empty theirs: the owners' loops then
+        // run side by side instead of one group at a time
+        if (__ballot(filled > SIFT_DESC_BUF - 16 || (base + 16 >= len && filled > 0)) != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int cnt = filled;
+            const int max_cnt = max(max(__shfl(cnt, 0), __shfl(cnt, 16)), max(__shfl(cnt, 32), __shfl(cnt, 48)));
+            for (int sidx = 0; sidx < max_cnt; ++sidx) {
+                if (sidx < cnt) {
+                    const int cl = s_cell[g][sidx];
+                    // the sample touches cells b, b + 1, b + 6, b + 7 of the 6x6 grid (b + 1 stays in b's row: c0 + 1 <= 4)
+                    const unsigned t = (unsigned)(my_cell - (cl >> 8));
+                    if (t < 8u && ((0xC3u >> t) & 1u)) {
+                        const int o0 = cl & 255, q = (int)((t >> 2) * 4 + (t & 1u) * 2);      // 4 * dr + 2 * dc
+                        mine[o0] += s_v[g][sidx][q];
+                        mine[o0 + 1] += s_v[g][sidx][q + 1];
                     }
                 }
             }
-            __syncthreads();
             filled = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    __syncthreads();
-    // circular orientation bins, then the 128 values
-    if (lane < d * d) {
-        const int i = lane / d, j = lane % d;
-        float *hc = hist + ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-        hc[0] += hc[n];
-        hc[1] += hc[n + 1];
-        for (int k = 0; k < n; ++k) s_dst[(i * d + j) * n + k] = hc[k];
-    }
-    __syncthreads();
+    // circular orientation bins, then the 128 values in (row, column, bin) order
+    mine[0] += mine[n];
+    mine[1] += mine[n + 1];
+    for (int k = 0; k < n; ++k) s_dst[g][gl * n + k] = mine[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int L = d * d * n;
-    if (lane == 0) {
+    if (gl == 0) {
         float nrm2 = 0;
-        for (int k = 0; k < L; ++k) nrm2 += s_dst[k] * s_dst[k];
+        for (int k = 0; k < L; ++k) nrm2 += s_dst[g][k] * s_dst[g][k];
         const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
         nrm2 = 0;
         for (int k = 0; k < L; ++k) {
-            const float v = s_dst[k] < thr ? s_dst[k] : thr;
-            nrm2 += v * v;
+            const float vv = s_dst[g][k] < thr ? s_dst[g][k] : thr;
+            nrm2 += vv * vv;
         }
         const float sq = sqrtf(nrm2);
-        s_scale[0] = thr;
-        s_scale[1] = SIFT_INT_DESCR_FCTR / (sq > SIFT_FLT_EPSILON ? sq : SIFT_FLT_EPSILON);
+        s_scale[g][0] = thr;
+        s_scale[g][1] = SIFT_INT_DESCR_FCTR / (sq > SIFT_FLT_EPSILON ? sq : SIFT_FLT_EPSILON);
     }
-    __syncthreads();
-    for (int k = lane; k < L; k += 64) {
-        const float v = s_dst[k] < s_scale[0] ? s_dst[k] : s_scale[0];
-        int q = sift_round_f(v * s_scale[1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!has) return;
+    for (int k = gl; k < L; k += 16) {
+        const float vv = s_dst[g][k] < s_scale[g][0] ? s_dst[g][k] : s_scale[g][0];
+        int q = sift_round_f(vv * s_scale[g][1]);
         q = q < 0 ? 0 : (q > 255 ? 255 : q);
-        desc[(size_t)blockIdx.x * L + k] = (float)q;
+        desc[(size_t)jb.out * L + k] = (float)q;
     }
 }
 
@@ -461,7 +510,7 @@ static int sift_blur(vo_ctx *ctx, const float *src, float *dst, float *tmp, int 
     int rc = sift_gauss_kernel(sigma, K);
     if (rc) return rc;
     hipLaunchKernelGGL(sift_blur_rows_kernel, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, tmp, w, h, K);
-    hipLaunchKernelGGL(sift_blur_cols_kernel, dim3((w + 255) / 256, (h + SIFT_COL_ROWS - 1) / SIFT_COL_ROWS), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(sift_blur_cols_kernel, dim3((w + 63) / 64, (h + SIFT_COL_ROWS - 1) / SIFT_COL_ROWS), dim3(256), 0, ctx->stream,
                        (const float *)tmp, dst, w, h, K);
     return VO_OK;
 }
@@ -629,18 +678,47 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
     std::vector<vo_sift_keypoint> kps((size_t)h_cnt[1]);
     if (h_cnt[1]) {
-        VO_HIP_CHECK(hipMemcpyAsync(kps.data(), d_kp, kps.size() * sizeof(vo_sift_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+        void *pin;      // through page-locked memory: a copy into pageable memory is staged in small pieces
+        if ((rc = vo_pinned_reserve(ctx, kps.size() * sizeof(vo_sift_keypoint), &pin))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(pin, d_kp, kps.size() * sizeof(vo_sift_keypoint), hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(kps.data(), pin, kps.size() * sizeof(vo_sift_keypoint));
     }
-    // KeyPointsFilter::removeDuplicatedSorted: order by (x, y, size desc, angle, response desc, octave desc), drop repeats
-    std::sort(kps.begin(), kps.end(), [](const vo_sift_keypoint &a, const vo_sift_keypoint &b) {
-        if (a.x != b.x) return a.x < b.x;
-        if (a.y != b.y) return a.y < b.y;
-        if (a.size != b.size) return a.size > b.size;
-        if (a.angle != b.angle) return a.angle < b.angle;
-        if (a.response != b.response) return a.response > b.response;
-        return a.octave > b.octave;
-    });
+    // KeyPointsFilter::removeDuplicatedSorted: order by (x, y, size desc, angle, response desc, octave desc), drop repeats.
+    // Coordinates are non-negative floats, whose bit patterns order like the values: one 64-bit key sorts by (x, y);
+    // runs of equal keys (a keypoint with several orientations) are then put in the full order.
+    {
+        const auto full_less = [](const vo_sift_keypoint &a, const vo_sift_keypoint &b) {
+            if (a.x != b.x) return a.x < b.x;
+            if (a.y != b.y) return a.y < b.y;
+            if (a.size != b.size) return a.size > b.size;
+            if (a.angle != b.angle) return a.angle < b.angle;
+            if (a.response != b.response) return a.response > b.response;
+            return a.octave > b.octave;
+        };
+        bool plain = true;
+        for (const auto &k : kps) plain = plain && k.x >= 0 && k.y >= 0;       // always true for SIFT; NaN or negative: full sort
+        if (plain) {
+            std::vector<std::pair<uint64_t, uint32_t>> order(kps.size());
+            for (size_t i = 0; i < kps.size(); ++i) {
+                uint32_t bx, by;
+                memcpy(&bx, &kps[i].x, 4); memcpy(&by, &kps[i].y, 4);
+                order[i] = {((uint64_t)bx << 32) | by, (uint32_t)i};
+            }
+            std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a.first < b.first; });
+            std::vector<vo_sift_keypoint> sorted(kps.size());
+            for (size_t i = 0; i < kps.size(); ++i) sorted[i] = kps[order[i].second];
+            for (size_t i = 0; i < sorted.size();) {
+                size_t j = i + 1;
+                while (j < sorted.size() && order[j].first == order[i].first) ++j;
+                if (j - i > 1) std::sort(sorted.begin() + i, sorted.begin() + j, full_less);
+                i = j;
+            }
+            kps.swap(sorted);
+        } else {
+            std::sort(kps.begin(), kps.end(), full_less);
+        }
+    }
     size_t m = 0;
     for (size_t i = 0; i < kps.size(); ++i) {
         if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle)
@@ -671,12 +749,13 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         if (fabsf(angle - 360.f) < SIFT_FLT_EPSILON) angle = 0.f;
         SiftJob &jb = jobs[i];
         jb.octave = octave - first_octave;
+        jb.out = (int)i;
         jb.layer = layer;
         jb.px = (int)lrint((double)ptx);
         jb.py = (int)lrint((double)pty);
         jb.ori = angle;
-        float cos_t = (float)cos((double)(angle * (float)(3.14159265358979323846 / 180.))),
-              sin_t = (float)sin((double)(angle * (float)(3.14159265358979323846 / 180.)));
+        const float cos_t = (float)cos((double)(angle * (float)(3.14159265358979323846 / 180.))),
+                    sin_t = (float)sin((double)(angle * (float)(3.14159265358979323846 / 180.)));
         const float hist_width = SIFT_DESCR_SCL_FCTR * scl;
         int radius = (int)lrint((double)(hist_width * 1.4142135623730951f * (d + 1) * 0.5f));
         const int w = O.w[jb.octave], h = O.h[jb.octave];
@@ -685,6 +764,8 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         jb.cos_t = cos_t / hist_width;
         jb.sin_t = sin_t / hist_width;
     }
+    // a wavefront serves four keypoints and lasts as long as the largest of their windows: neighbours of equal size
+    std::stable_sort(jobs.begin(), jobs.end(), [](const SiftJob &a, const SiftJob &b) { return a.radius > b.radius; });
     if ((rc = vo_stage_reserve(ctx, 4, n_out * sizeof(SiftJob), &p))) return rc;
     SiftJob *d_jobs = (SiftJob *)p;
     float *d_desc = descriptors;
@@ -692,14 +773,18 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         if ((rc = vo_stage_reserve(ctx, 5, n_out * 128 * 4, &p))) return rc;
         d_desc = (float *)p;
     }
-    // pageable source: the copy is staged before the call returns, so `jobs` may go out of scope afterwards
-    VO_HIP_CHECK(hipMemcpy(d_jobs, jobs.data(), n_out * sizeof(SiftJob), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)n_out), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
+    {
+        void *pin;
+        if ((rc = vo_pinned_reserve(ctx, n_out * sizeof(SiftJob), &pin))) return rc;
+        memcpy(pin, jobs.data(), n_out * sizeof(SiftJob));
+        VO_HIP_CHECK(hipMemcpyAsync(d_jobs, pin, n_out * sizeof(SiftJob), hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
                        (const SiftJob *)d_jobs, (int)n_out, d_desc);
     VO_HIP_CHECK(hipGetLastError());
-    if (mem == VO_MEM_HOST) {
+    if (mem == VO_MEM_HOST)
         VO_HIP_CHECK(hipMemcpyAsync(descriptors, d_desc, n_out * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
+    // the page-locked job list must stay untouched until the kernel has read its copy: wait in both memory modes
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
