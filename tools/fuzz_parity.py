@@ -105,6 +105,64 @@ def main():
             ri, rd, rk = oracle.knn_match2(x, y, ratio)
             assert (gi == ri).all() and (gd.view(np.uint32) == rd.view(np.uint32)).all() and (gk == rk).all(), ("match", seed, n1, n2)
     print(json.dumps({"op": "knn_match2", "seeds": a.seeds, "bit_exact": True}), flush=True)
+    # connected components in both numberings, and the fused FeatureExtractor.harris call
+    labels_seen = 0
+    for seed in range(a.seeds):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 500))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            mask = (rng.random((h, w)) < rng.uniform(0.02, 0.9)).astype(np.uint8) * int(rng.integers(1, 256))
+        elif kind == 1:
+            mask = np.zeros((h, w), np.uint8); mask[::int(rng.integers(1, 4)), ::int(rng.integers(1, 4))] = 255
+        elif kind == 2 and h >= 3 and w >= 3:
+            mask = oracle.harris_mask(synth.frame_pair((max(h, 24), max(w, 24)), seed=500 + seed)[0], 0.1, float(rng.uniform(0.001, 0.2)))
+        else:
+            mask = (np.add.outer(np.arange(h), np.arange(w)) % int(rng.integers(2, 9)) == 0).astype(np.uint8)      # diagonals
+        for order in (0, 1):
+            n, lab, cen, ar = hip.connected_components(ctx, mask, order)
+            rn, rl, rc, ra = oracle.connected_components(mask, order)
+            assert n == rn and (lab == rl).all() and (ar == ra).all() and (cen.view(np.uint64) == rc.view(np.uint64)).all(), ("cc", seed, order)
+            labels_seen += n
+        hh, ww = int(rng.integers(8, 260)), int(rng.integers(8, 400))
+        img = synth.frame_pair((max(hh, 24), max(ww, 24)), seed=600 + seed)[0][:hh, :ww].copy()
+        order = int(rng.integers(0, 2))
+        got, ref = hip.harris_corners(ctx, img, order=order), oracle.harris_corners(img, order=order)
+        assert got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all(), ("harris_corners", seed)
+    print(json.dumps({"op": "connected_components/harris_corners", "seeds": a.seeds, "labels": labels_seen, "bit_exact": True}), flush=True)
+    # SIFT: keypoints (six fields) and descriptors
+    kp_seen = 0
+    for seed in range(a.seeds):
+        h, w = int(rng.integers(24, 260)), int(rng.integers(24, 400))
+        img = synth.frame_pair((h, w), seed=700 + seed, noise=float(rng.uniform(0.2, 4.0)))[0]
+        args = dict(n_octave_layers=int(rng.integers(2, 6)), contrast_threshold=float(rng.uniform(0.01, 0.08)),
+                    edge_threshold=float(rng.uniform(4, 20)), sigma=float(rng.uniform(1.0, 2.2)))
+        rk, rd = oracle.sift(img, **args)
+        kp, des = hip.sift_detect_compute(ctx, img, **args)
+        assert len(kp) == len(rk), ("sift count", seed, len(kp), len(rk))
+        for f in ("x", "y", "size", "angle", "response"):
+            assert (kp[f].view(np.uint32) == rk[f].view(np.uint32)).all(), ("sift", seed, f)
+        assert (kp["octave"] == rk["octave"]).all() and (des == rd).all(), ("sift descriptors", seed)
+        kp_seen += len(kp)
+    print(json.dumps({"op": "sift_detect_compute", "seeds": a.seeds, "keypoints": kp_seen, "bit_exact": True}), flush=True)
+    # two-view cheirality vote
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    from oracle import solvers_np
+    worst_cloud = 0.0
+    for seed in range(min(a.seeds, 12)):
+        n = int(rng.integers(1, 400))
+        sc = synth.two_view_scene(n=n, seed=seed, inlier_frac=1.0, noise=float(rng.uniform(0, 0.3)))
+        Kf = sc["K"].astype(np.float32)
+        motions = BootstrapInitializer.motion_hypotheses(Kf.T @ sc["F"] @ Kf)
+        M1, M2 = Kf @ np.eye(3, 4, dtype=np.float32), np.stack([Kf @ m for m in motions])
+        p1 = np.hstack([sc["m1"], np.ones((n, 1), np.float32)]).astype(np.float32)
+        p2 = np.hstack([sc["m2"], np.ones((n, 1), np.float32)]).astype(np.float32)
+        clouds, votes = hip.cheirality_vote(ctx, p1, p2, M1, M2, motions)
+        rc, rv = solvers_np.cheirality_votes(p1, p2, M1, M2, motions)
+        assert (votes == rv).all(), ("cheirality votes", seed)
+        rel = np.abs(clouds - rc)[..., :3] / np.maximum(np.abs(rc[..., :3]), 1.0)
+        worst_cloud = max(worst_cloud, float(np.median(rel)))
+        assert np.median(rel) < 1e-5, ("cheirality clouds", seed)
+    print(json.dumps({"op": "cheirality_vote", "seeds": min(a.seeds, 12), "votes_exact": True, "worst_median_rel_cloud_dev": worst_cloud}), flush=True)
 
 
 if __name__ == "__main__":
