@@ -304,6 +304,31 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, in
                                int max_iters, uint64_t *rng_state, double *F_out, uint8_t *inlier_mask,
                                int32_t *n_inliers);
 
+/* ---- one tracked frame: tracker, status filter and PnP-RANSAC in one call ---------------------------
+ * vo_track_pnp replaces the body of ContinuousVO._process_frame up to the pose
+ * (vo_pipeline/continuousVO.py:160-180): cv.calcOpticalFlowPyrLK from `prev` to `next`
+ * (vo_pipeline/poseEstimation.py:116-133), the status == 1 filter of keypoints and landmarks
+ * (continuousVO.py:168-172) and cv.solvePnPRansac with its refit on the survivors
+ * (poseEstimation.py:51-77) -- with one synchronisation instead of the three round trips of the separate
+ * calls.  The outcome is that of vo_klt_track (init_pts = NULL) followed by vo_solve_pnp_ransac on the rows
+ * with status 1, in their order.  prev / next: built pyramids of one image each.  prev_pts (n,2) float32 and
+ * landmarks (n,3) float32, row i of one belonging to row i of the other; next_pts (n,2) float32, status (n)
+ * uint8 as vo_klt_track returns them; inlier_mask (n) uint8 over the INPUT rows (0 for rows that were not
+ * tracked); all five follow `mem`.  *n_tracked (host) = rows with status 1, *n_inliers (host) = 0 when no pose
+ * was found (fewer than four survivors, no valid sample), and Rt_out (12 doubles, host, row-major [R|t]) is
+ * then left untouched.  K, thr, conf, max_iters, refine_iters, rng_state as in vo_solve_pnp_ransac.  Always
+ * synchronises the stream (the pose returns to the host).
+ */
+int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
+                 int n, const vo_klt_params *params, const double *K, double thr, double conf, int max_iters,
+                 int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
+                 uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int mem);
+/* How the context's last vo_track_pnp call ended (no counterpart in the reference; for tests and profiling):
+ * 0 no pose was sought (fewer than four survivors), 1 within the first 256 samples, on the single
+ * synchronisation, 2 the loop asked for more samples and vo_solve_pnp_ransac finished on the device-resident
+ * survivors, 3 the same because the device-side sampler or replay could not vouch for its result. */
+int vo_track_pnp_path(const vo_ctx *ctx);
+
 /* ---- corner mask and sub-pixel refinement of FeatureExtractor.harris -------------------------
  * vo_harris_mask replaces cv.cornerHarris + cv.dilate + cv.threshold + np.uint8
  * (vo_pipeline/featureExtraction.py:40-43): mask = 255 where the 3x3 maximum of the response

@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--dataset-params", default="PARKING")
     ap.add_argument("--bootstrap", default="sift", choices=["sift", "klt"],
                     help="correspondences of the two-view bootstraps: SIFT + matching (the reference's route) or corners + KLT")
+    ap.add_argument("--separate-calls", action="store_true", help="KLT and PnP as two calls per tracked frame, as the reference makes them")
+    ap.add_argument("--profile", action="store_true", help="median time of each part of a tracked frame's step")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
     if a.v:
@@ -131,7 +133,8 @@ def main():
     data = loadData.synthetic_parking(a.frames, a.seed)
     frames = list(data.frames)                   # rendering is not part of the timed loop
     data.frames = iter(frames)
-    vo = ContinuousVO(data, rescale_bootstrap=True, bootstrap_correspondences=a.bootstrap)   # one world scale across keyframes, so the path compares with ground truth
+    vo = ContinuousVO(data, rescale_bootstrap=True, bootstrap_correspondences=a.bootstrap,
+                      fused_step=not a.separate_calls)   # one world scale across keyframes, so the path compares with ground truth
     calls = []
     if a.cpu_baseline:
         from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation
@@ -151,6 +154,29 @@ def main():
 
         PoseEstimation.KLT = staticmethod(klt_rec)
         PoseEstimation.PnP = pnp_rec
+    parts = {}
+    if a.profile:
+        from visual_odometry_amd.vo_pipeline import continuousVO as cvo, keypointTrajectory as kt
+        from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation as PE
+
+        def timed(owner, name, label, static=False):
+            fn = getattr(owner, name)
+
+            def wrapper(*args, **kw):
+                t0 = time.perf_counter()
+                out = fn(*args, **kw)
+                parts.setdefault(label, []).append(time.perf_counter() - t0)
+                return out
+            setattr(owner, name, staticmethod(wrapper) if static else wrapper)
+        timed(PE, "KLT", "KLT", static=True)
+        timed(PE, "PnP", "PnP")
+        timed(cvo, "filter_tracked", "filter_tracked")
+        timed(cvo, "baseline_uncertainty", "baseline_uncertainty")
+        timed(kt.KeypointTrajectories, "at_frame", "at_frame")
+        timed(kt.KeypointTrajectories, "tracked_to_many", "tracked_to_many")
+        for name in ("track_and_pose",):
+            if hasattr(PE, name):
+                timed(PE, name, name)
     per_frame = []
     while True:
         t0 = time.perf_counter()
@@ -164,12 +190,13 @@ def main():
     if a.cpu_baseline and calls:
         step = max(1, len(calls) // a.cpu_baseline)
         out_cpu = {"cpu_baseline": cpu_frame_baseline(calls[::step][:a.cpu_baseline], np.asarray(data.K, np.float64))}
-    print(json.dumps({"frames": len(per_frame), "bootstrap": a.bootstrap, "keyframes": [k.idx for k in vo.keyframes],
+    print(json.dumps({"frames": len(per_frame), "bootstrap": a.bootstrap, "fused_step": not a.separate_calls, "keyframes": [k.idx for k in vo.keyframes],
                       "loop_frames_per_s": float(len(tracked) / tracked.sum()),
                       "median_ms_per_tracked_frame": float(np.median(tracked) * 1e3),
                       "bootstrap_ms": float(per_frame[vo.frames_to_skip] * 1e3),
                       "rel_position_rms": rel, "max_rotation_deg": rot, "scale": scale,
-                      "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu}))
+                      "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
+                      **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()}} if parts else {})}))
 
 
 if __name__ == "__main__":

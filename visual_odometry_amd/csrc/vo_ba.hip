@@ -533,15 +533,64 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 #define REFINE_THREADS 512
 struct Pose6 { double v[6]; };
 
+// Rotation vector of a rotation matrix (row-major 3x3 inside a 3x4 [R|t], row pitch 4) via the unit quaternion,
+// largest component first for accuracy near 0 and pi.
+__device__ static void rotvec_of_Rt(const double *Rt, double *rv)
+{
+    const double R0 = Rt[0], R1 = Rt[1], R2 = Rt[2], R3 = Rt[4], R4 = Rt[5], R5 = Rt[6], R6 = Rt[8], R7 = Rt[9], R8 = Rt[10];
+    const double tr = R0 + R4 + R8;
+    double q0, q1, q2, q3;   // x, y, z, w
+    if (tr > R0 && tr > R4 && tr > R8) {
+        q3 = 1. + tr; q0 = R7 - R5; q1 = R2 - R6; q2 = R3 - R1;
+    } else if (R0 >= R4 && R0 >= R8) {
+        q0 = 1. + 2. * R0 - tr; q1 = R1 + R3; q2 = R2 + R6; q3 = R7 - R5;
+    } else if (R4 >= R8) {
+        q1 = 1. + 2. * R4 - tr; q0 = R1 + R3; q2 = R5 + R7; q3 = R2 - R6;
+    } else {
+        q2 = 1. + 2. * R8 - tr; q0 = R2 + R6; q1 = R5 + R7; q3 = R3 - R1;
+    }
+    const double nq = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    q0 /= nq; q1 /= nq; q2 /= nq; q3 /= nq;
+    if (q3 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+    const double sn = sqrt(q0 * q0 + q1 * q1 + q2 * q2);
+    const double angle = 2. * atan2(sn, q3);
+    const double scale = sn < 1e-12 ? 2. : angle / sn;     // angle / sin(angle / 2) -> 2
+    rv[0] = scale * q0; rv[1] = scale * q1; rv[2] = scale * q2;
+}
+
+// Start pose: `start` (rotation vector, translation), or -- when Rt_src is given -- the [R|t] at
+// Rt_src + 12 * (sel_dev ? *sel_dev : sel), converted on the device (a negative index: nothing to refine, NaN out).
+// n_dev (optional): the number of correspondences lives on the device.
 __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float *__restrict__ X, const float *__restrict__ x,
                                                                      const uint8_t *__restrict__ mask, int n, BaK K, Pose6 start,
-                                                                     int max_iters, double *__restrict__ out)
+                                                                     int max_iters, double *__restrict__ out,
+                                                                     const double *__restrict__ Rt_src, int sel,
+                                                                     const int *__restrict__ sel_dev, const int *__restrict__ n_dev)
 {
     __shared__ double red[REFINE_THREADS / 64][28];
     __shared__ double tot[28];
     __shared__ double cam_s[6];
     __shared__ int stop_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n_dev) n = *n_dev;
+    if (Rt_src) {
+        if (sel_dev) sel = *sel_dev;
+        if (sel < 0) {
+            if (tid < 8) out[tid] = __builtin_nan("");
+            return;
+        }
+        if (tid == 0) {
+            const double *Rt = Rt_src + 12 * (int64_t)sel;
+            double rv[3];
+            rotvec_of_Rt(Rt, rv);
+            cam_s[0] = rv[0]; cam_s[1] = rv[1]; cam_s[2] = rv[2];
+            cam_s[3] = Rt[3]; cam_s[4] = Rt[7]; cam_s[5] = Rt[11];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) start.v[k] = cam_s[k];
+        __syncthreads();
+    }
     double cam[6], prev_cam[6], prev_cost = __builtin_inf(), last_cost = __builtin_inf();
 #pragma unroll
     for (int k = 0; k < 6; ++k) { cam[k] = start.v[k]; prev_cam[k] = start.v[k]; }
@@ -676,7 +725,28 @@ int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, c
     void *p;
     if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
     double *d_out = (double *)p;
-    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out);
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
+                       (const double *)nullptr, 0, (const int *)nullptr, (const int *)nullptr);
+    VO_HIP_CHECK(hipGetLastError());
+    VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return VO_OK;
+}
+
+// The refit started from a candidate that lives on the device: [R|t] number sel (or *sel_dev) of dRt; the number of
+// correspondences may live on the device too (n_dev, bounded by n).  Enqueues the copy of {pose (6), cost,
+// iterations} into host_out (page-locked); no synchronisation.
+int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
+                                 const double *K, const double *dRt, int sel, const int *sel_dev, int max_iters, double *host_out)
+{
+    BaK Kv;
+    memcpy(Kv.k, K, sizeof(Kv.k));
+    Pose6 start = {};
+    int rc;
+    void *p;
+    if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
+    double *d_out = (double *)p;
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
+                       dRt, sel, sel_dev, n_dev);
     VO_HIP_CHECK(hipGetLastError());
     VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;

@@ -1,0 +1,392 @@
+// One tracked frame of the pipeline in one call with one synchronisation: the body of
+// ContinuousVO._process_frame up to the pose (vo_pipeline/continuousVO.py:160-180) --
+//   cv.calcOpticalFlowPyrLK (PoseEstimation.KLT, vo_pipeline/poseEstimation.py:116-133),
+//   the status == 1 filter of keypoints and landmarks (continuousVO.py:168-172),
+//   cv.solvePnPRansac with its refit (PoseEstimation.PnP, poseEstimation.py:51-77).
+// Called one after the other, the three steps cost three round trips to the host: the tracker's results come
+// back to be filtered, the sampler needs the number of survivors, the RANSAC loop reads the inlier counts.  Here
+// the survivors are compacted on the device, the first 256 samples are drawn on the device from the generator's
+// raw output (which does not depend on the point count; only the modulus and the rejections do), the loop over
+// their inlier counts is replayed by one wavefront, and the winner's mask and refit are launched on an index that
+// still lives on the device.  The host reads everything back once, replays the loop itself on the returned counts
+// (its own libm decides the adaptive bound) and, when the loop needs more than the first chunk, when the device's
+// replay disagrees, or when the raw draws ran out, finishes with vo_solve_pnp_ransac on the compacted points.
+// Either way the outcome is that of vo_klt_track followed by vo_solve_pnp_ransac on the rows with status 1.
+#include "vo_internal.h"
+#include <math.h>
+#include <float.h>
+
+#define FS_THREADS 1024
+#define FS_SAMPLES 256                      // samples of the first chunk
+#define FS_DRAWS (4 * FS_SAMPLES + 512)     // raw generator outputs kept on the device: room for 512 rejected draws
+
+struct FrameMeta {
+    int m;            // correspondences with status 1
+    int win;          // winning sample of the first chunk, -1: none
+    int best;         // its inlier count
+    int niters;       // the loop's iteration bound after the first chunk
+    int overflow;     // the raw draws did not suffice for FS_SAMPLES subsets
+    int pad[3];
+    double Rt[12];    // the winner
+};
+
+// Rows with status 1, in order: landmarks and tracked points side by side.  One workgroup.
+__global__ __launch_bounds__(FS_THREADS) void frame_compact_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
+                                                                   const float *__restrict__ pts, int n, float *__restrict__ Xc,
+                                                                   float *__restrict__ xc, FrameMeta *__restrict__ meta)
+{
+    __shared__ int wcount[FS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
+        const int i = i0 + tid;
+        const bool keep = i < n && status[i] == 1;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wcount[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < FS_THREADS / 64; ++w) {
+            const int c = wcount[w];
+            before += w < wv ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const int64_t j = base + before + __popcll(b & ((1ull << lane) - 1));
+            Xc[3 * j] = X[3 * (int64_t)i]; Xc[3 * j + 1] = X[3 * (int64_t)i + 1]; Xc[3 * j + 2] = X[3 * (int64_t)i + 2];
+            xc[2 * j] = pts[2 * (int64_t)i]; xc[2 * j + 1] = pts[2 * (int64_t)i + 1];
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        meta->m = base;
+        meta->win = -1;
+        meta->best = 0;
+        meta->niters = 0;
+        meta->overflow = 0;
+    }
+}
+
+// One subset of four distinct indices drawn from position p of the raw generator output, as
+// RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another draw.
+// Returns the position after the subset; FS_DRAWS when the draws ran out (a subset whose last draw is the
+// buffer's last entry counts as ran out too, which keeps the two cases apart at no cost but one subset).
+__device__ static inline int frame_draw_subset(const uint32_t *raw, int p, uint32_t m, int *idx)
+{
+    int have = 0;
+    while (have < 4 && p < FS_DRAWS) {
+        const int j = (int)(raw[p++] % m);
+        bool dup = false;
+        for (int k = 0; k < have; ++k) dup = dup || idx[k] == j;
+        if (!dup) idx[have++] = j;
+    }
+    return have == 4 && p < FS_DRAWS ? p : FS_DRAWS;
+}
+
+// Subsets 0 .. c0-1.  Where subset i starts depends on the rejections before it; "the position after the subset
+// that starts at p" is a function of p alone, so the starts are the orbit of 0 under it: every position computes its
+// successor, log2(c0) rounds of pointer doubling give hops of 1, 2, 4, ... subsets, and sample i combines the hops of
+// its set bits.  One workgroup.
+__global__ __launch_bounds__(FS_THREADS) void frame_sample_kernel(const uint32_t *__restrict__ raw_g, FrameMeta *__restrict__ meta,
+                                                                  int c0, int *__restrict__ subsets)
+{
+    __shared__ uint32_t raw[FS_DRAWS];
+    __shared__ unsigned short hop[2][FS_DRAWS + 1];
+    const int tid = threadIdx.x;
+    const int m = meta->m;
+    if (m < 4) {
+        if (tid < c0) { subsets[4 * tid] = 0; subsets[4 * tid + 1] = 0; subsets[4 * tid + 2] = 0; subsets[4 * tid + 3] = 0; }
+        return;
+    }
+    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = raw_g[p];
+    __syncthreads();
+    int idx[4];
+    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) hop[0][p] = (unsigned short)frame_draw_subset(raw, p, (uint32_t)m, idx);
+    if (tid == 0) { hop[0][FS_DRAWS] = FS_DRAWS; hop[1][FS_DRAWS] = FS_DRAWS; }
+    __syncthreads();
+    int pos = 0, cur = 0;
+    for (int k = 0; (1 << k) < c0; ++k) {
+        if (tid < c0 && ((tid >> k) & 1)) pos = hop[cur][pos];
+        for (int p = tid; p < FS_DRAWS; p += FS_THREADS) hop[cur ^ 1][p] = hop[cur][hop[cur][p]];
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid < c0) {
+        idx[0] = idx[1] = idx[2] = idx[3] = 0;
+        const int end = pos < FS_DRAWS ? frame_draw_subset(raw, pos, (uint32_t)m, idx) : FS_DRAWS;
+        if (end >= FS_DRAWS) {
+            meta->overflow = 1;
+            idx[0] = idx[1] = idx[2] = idx[3] = 0;
+        }
+        subsets[4 * tid] = idx[0]; subsets[4 * tid + 1] = idx[1]; subsets[4 * tid + 2] = idx[2]; subsets[4 * tid + 3] = idx[3];
+    }
+}
+
+// RANSACUpdateNumIters
+__device__ static int frame_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = fmin(fmax(p, 0.), 1.);
+    ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)lrint(num / denom);
+}
+
+// OpenCV's sequential loop over the first chunk's candidates, by one wavefront: candidate c improves the best when
+// its count exceeds max(best, 3) and c is still below the iteration bound, which every improvement recomputes.
+// Only improvements change the state, so per 64 candidates the wavefront jumps from one improvement to the next.
+__global__ __launch_bounds__(64) void frame_replay_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid, int c0,
+                                                          int max_iters, double conf, const double *__restrict__ Rt,
+                                                          FrameMeta *__restrict__ meta)
+{
+    const int lane = threadIdx.x;
+    const int m = meta->m;
+    int niters = max_iters, best = -1, best_c = -1;
+    bool stop = m < 4;
+    for (int r = 0; r * 64 < c0 && !stop; ++r) {
+        const int c = r * 64 + lane;
+        const int v = (c < c0 && valid[c]) ? counts[c] : -1;
+        while (true) {
+            const int bar = best > 3 ? best : 3;
+            const unsigned long long b = __ballot(v > bar);
+            if (!b) break;
+            const int first = __ffsll((long long)b) - 1;
+            if (r * 64 + first >= niters) { stop = true; break; }
+            best = __shfl(v, first);
+            best_c = r * 64 + first;
+            niters = frame_update_num_iters(conf, (double)(m - best) / m, 4, niters);
+        }
+    }
+    if (lane == 0) {
+        meta->win = best_c;
+        meta->best = best_c >= 0 ? best : 0;
+        meta->niters = niters;
+    }
+    if (best_c >= 0 && lane < 12) meta->Rt[lane] = Rt[12 * (int64_t)best_c + lane];
+}
+
+// rank[i] = row of correspondence i among the survivors, -1 for the others (the compaction's inverse)
+__global__ __launch_bounds__(FS_THREADS) void frame_rank_kernel(const uint8_t *__restrict__ status, int n, int *__restrict__ rank)
+{
+    __shared__ int wcount[FS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
+        const int i = i0 + tid;
+        const bool keep = i < n && status[i] == 1;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wcount[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < FS_THREADS / 64; ++w) {
+            const int c = wcount[w];
+            before += w < wv ? c : 0;
+            total += c;
+        }
+        if (i < n) rank[i] = keep ? base + before + __popcll(b & ((1ull << lane) - 1)) : -1;
+        base += total;
+        __syncthreads();
+    }
+}
+
+// The survivors' inlier mask spread back over all correspondences; zero when there is no winner.
+__global__ void frame_expand_kernel(const int *__restrict__ rank, const uint8_t *__restrict__ mask_c, int n,
+                                    const FrameMeta *__restrict__ meta, int use_meta, uint8_t *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool none = use_meta && meta->win < 0;
+    const int j = rank[i];
+    mask[i] = (!none && j >= 0) ? mask_c[j] : 0;
+}
+
+// cv::RNG raw outputs from `state` on (multiply-with-carry), FS_DRAWS of them, kept on the device per context
+static int frame_raw_draws(vo_ctx *ctx, uint64_t state, const uint32_t **out)
+{
+    void *p;
+    int rc;
+    if ((rc = vo_stage_reserve(ctx, 9, sizeof(uint32_t) * FS_DRAWS, &p))) return rc;
+    if (!ctx->rng_raw_ok || ctx->rng_raw_seed != state || ctx->rng_raw_dev != p) {
+        uint64_t s = state;
+        for (int k = 0; k < FS_DRAWS; ++k) {
+            s = (uint64_t)(uint32_t)s * 4164903690u + (s >> 32);
+            ctx->rng_raw_host[k] = (uint32_t)s;
+        }
+        VO_HIP_CHECK(hipMemcpyAsync(p, ctx->rng_raw_host, sizeof(uint32_t) * FS_DRAWS, hipMemcpyHostToDevice, ctx->stream));
+        ctx->rng_raw_seed = state;
+        ctx->rng_raw_dev = p;
+        ctx->rng_raw_ok = true;
+    }
+    *out = (const uint32_t *)p;
+    return VO_OK;
+}
+
+static void frame_matrix_from_rotvec(const double *rv, double *R)
+{
+    const double th = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (th == 0) { for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0); return; }
+    const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1. - c;
+    R[0] = c + v * kx * kx;      R[1] = v * kx * ky - s * kz; R[2] = v * kx * kz + s * ky;
+    R[3] = v * kx * ky + s * kz; R[4] = c + v * ky * ky;      R[5] = v * ky * kz - s * kx;
+    R[6] = v * kx * kz - s * ky; R[7] = v * ky * kz + s * kx; R[8] = c + v * kz * kz;
+}
+
+extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
+                            int n, const vo_klt_params *klt, const double *K, double thr, double conf, int max_iters,
+                            int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
+                            uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int mem)
+{
+    VO_REQUIRE(ctx && prev && next && klt && K && Rt_out && n_tracked && n_inliers, "vo_track_pnp: NULL argument");
+    VO_REQUIRE(n >= 0 && (n == 0 || (prev_pts && landmarks && next_pts && status && inlier_mask)), "vo_track_pnp: bad buffers (n=%d)", n);
+    VO_REQUIRE(max_iters >= 1 && max_iters <= (1 << 22) && refine_iters >= 0, "vo_track_pnp: max_iters=%d refine_iters=%d", max_iters, refine_iters);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_track_pnp: bad mem flag %d", mem);
+    VO_REQUIRE(prev->batch == 1 && next->batch == 1, "vo_track_pnp: pyramids of one image each (batch %d, %d)", prev->batch, next->batch);
+    *n_tracked = 0;
+    *n_inliers = 0;
+    ctx->frame_path = 0;
+    if (n == 0) return VO_OK;
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const int c0 = max_iters < FS_SAMPLES ? max_iters : FS_SAMPLES;
+    const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
+    int rc;
+    const uint32_t *d_raw;
+    if ((rc = frame_raw_draws(ctx, state0, &d_raw))) return rc;
+    // one device block for everything that stays on the device between the steps
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const bool host = mem == VO_MEM_HOST;
+    const size_t o_pts = take(host ? (size_t)n * 8 : 0), o_X = take(host ? (size_t)n * 12 : 0), o_next = take(host ? (size_t)n * 8 : 0),
+                 o_status = take(host ? (size_t)n : 0), o_full = take(host ? (size_t)n : 0), o_Xc = take((size_t)n * 12),
+                 o_xc = take((size_t)n * 8), o_rank = take((size_t)n * 4), o_maskc = take((size_t)n), o_meta = take(sizeof(FrameMeta)),
+                 o_sub = take((size_t)c0 * 16), o_Rt = take((size_t)c0 * 96), o_counts = take((size_t)c0 * 4 + 16), o_valid = take((size_t)c0);
+    void *blk;
+    if ((rc = vo_stage_reserve(ctx, 8, off, &blk))) return rc;
+    char *base = (char *)blk;
+    const float *d_pts = host ? (const float *)(base + o_pts) : prev_pts;
+    const float *d_X = host ? (const float *)(base + o_X) : landmarks;
+    float *d_next = host ? (float *)(base + o_next) : next_pts;
+    uint8_t *d_status = host ? (uint8_t *)(base + o_status) : status;
+    uint8_t *d_full = host ? (uint8_t *)(base + o_full) : inlier_mask;
+    float *d_Xc = (float *)(base + o_Xc), *d_xc = (float *)(base + o_xc);
+    int *d_rank = (int *)(base + o_rank), *d_sub = (int *)(base + o_sub), *d_counts = (int *)(base + o_counts);
+    uint8_t *d_maskc = (uint8_t *)(base + o_maskc), *d_valid = (uint8_t *)(base + o_valid);
+    FrameMeta *d_meta = (FrameMeta *)(base + o_meta);
+    double *d_Rt = (double *)(base + o_Rt);
+    // page-locked read-back area
+    size_t poff = 0;
+    auto ptake = [&poff](size_t bytes) { const size_t o = poff; poff += (bytes + 63) & ~(size_t)63; return o; };
+    const size_t p_next = ptake(host ? (size_t)n * 8 : 0), p_status = ptake(host ? (size_t)n : 0), p_full = ptake(host ? (size_t)n : 0),
+                 p_meta = ptake(sizeof(FrameMeta)), p_counts = ptake((size_t)c0 * 4), p_valid = ptake((size_t)c0), p_ref = ptake(64);
+    void *pin;
+    if ((rc = vo_pinned_reserve(ctx, poff, &pin))) return rc;
+    char *hp = (char *)pin;
+    FrameMeta *h_meta = (FrameMeta *)(hp + p_meta);
+    double *h_ref = (double *)(hp + p_ref);
+    for (int k = 0; k < 8; ++k) h_ref[k] = NAN;
+
+    if (host) VO_HIP_CHECK(hipMemcpyAsync((void *)d_pts, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
+    // the landmarks are staged while the tracker runs
+    if (host) VO_HIP_CHECK(hipMemcpyAsync((void *)d_X, landmarks, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(frame_compact_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_Xc, d_xc, d_meta);
+    hipLaunchKernelGGL(frame_rank_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, n, d_rank);
+    VO_HIP_CHECK(hipGetLastError());
+    if (n >= 4) {
+        hipLaunchKernelGGL(frame_sample_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_raw, d_meta, c0, d_sub);
+        VO_HIP_CHECK(hipGetLastError());
+        if ((rc = vo_p3p_solve(ctx, d_Xc, d_xc, n, K, d_sub, c0, d_Rt, d_valid, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c0, nullptr, thr, d_counts, nullptr))) return rc;
+        hipLaunchKernelGGL(frame_replay_kernel, dim3(1), dim3(64), 0, ctx->stream, d_counts, d_valid, c0, max_iters, conf, d_Rt, d_meta);
+        VO_HIP_CHECK(hipGetLastError());
+        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, 1, &d_meta->win, thr, d_counts + c0, d_maskc))) return rc;
+        if (refine_iters > 0 &&
+            (rc = vo_refine_pose_from_Rt_async(ctx, d_Xc, d_xc, n, &d_meta->m, d_maskc, K, d_Rt, 0, &d_meta->win, refine_iters, h_ref)))
+            return rc;
+        hipLaunchKernelGGL(frame_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_rank, d_maskc, n, d_meta, 1, d_full);
+        VO_HIP_CHECK(hipGetLastError());
+        VO_HIP_CHECK(hipMemcpyAsync(hp + p_counts, d_counts, (size_t)c0 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(hp + p_valid, d_valid, (size_t)c0, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream));
+    }
+    VO_HIP_CHECK(hipMemcpyAsync(h_meta, d_meta, sizeof(FrameMeta), hipMemcpyDeviceToHost, ctx->stream));
+    if (host) {
+        VO_HIP_CHECK(hipMemcpyAsync(hp + p_next, d_next, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(hp + p_status, d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(hp + p_full, d_full, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const FrameMeta meta = *h_meta;
+    const int m = meta.m;
+    *n_tracked = m;
+    if (host) {
+        memcpy(next_pts, hp + p_next, (size_t)n * 8);
+        memcpy(status, hp + p_status, (size_t)n);
+    }
+    if (m < 4 || n < 4) {
+        if (host) memset(inlier_mask, 0, (size_t)n);
+        else if (n >= 4) { VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream)); VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+        return VO_OK;
+    }
+    // the host's own replay of the loop decides (its libm computes the adaptive bound OpenCV's would)
+    int hb, hbc, hn;
+    vo_ransac_replay_first_chunk((const int32_t *)(hp + p_counts), (const uint8_t *)(hp + p_valid), c0, m, 4, conf, max_iters, &hb, &hbc, &hn);
+    const bool finished = hn <= c0 || c0 >= max_iters;
+    const bool agree = !meta.overflow && hbc == meta.win && hn == meta.niters && (hbc < 0 || hb == meta.best);
+    if (finished && agree) {
+        ctx->frame_path = 1;
+        if (rng_state) {     // the generator after the iterations the loop ran, as OpenCV's own loop leaves it
+            const int ran = hn < max_iters ? hn : max_iters;
+            if ((rc = vo_ransac_advance_state(rng_state, m, 4, ran))) return rc;
+        }
+        if (hbc < 0) {
+            if (host) memset(inlier_mask, 0, (size_t)n);
+            return VO_OK;            // the expand kernel has zeroed a device-side mask
+        }
+        double Rt[12];
+        memcpy(Rt, meta.Rt, sizeof(Rt));
+        if (refine_iters > 0) {
+            bool finite = true;
+            for (int k = 0; k < 6; ++k) finite = finite && isfinite(h_ref[k]);
+            if (finite) {
+                double R[9];
+                frame_matrix_from_rotvec(h_ref, R);
+                for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[4 * r + c] = R[3 * r + c]; Rt[4 * r + 3] = h_ref[3 + r]; }
+            }
+        }
+        memcpy(Rt_out, Rt, sizeof(Rt));
+        if (host) memcpy(inlier_mask, hp + p_full, (size_t)n);
+        *n_inliers = hb;
+        return VO_OK;
+    }
+    // the loop wants more samples than the first chunk (or the fast path cannot vouch for its result): the whole
+    // RANSAC call on the survivors, which are already on the device
+    ctx->frame_path = !agree ? 3 : 2;
+    int32_t good = 0;
+    if ((rc = vo_solve_pnp_ransac(ctx, d_Xc, d_xc, m, K, thr, conf, max_iters, refine_iters, rng_state, Rt_out, d_maskc, &good, VO_MEM_DEVICE)))
+        return rc;
+    *n_inliers = good;
+    if (good == 0) {
+        if (host) memset(inlier_mask, 0, (size_t)n);
+        else { VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream)); VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+        return VO_OK;
+    }
+    hipLaunchKernelGGL(frame_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_rank, d_maskc, n, d_meta, 0, d_full);
+    VO_HIP_CHECK(hipGetLastError());
+    if (host) {
+        if ((rc = vo_pinned_reserve(ctx, (size_t)n, &pin))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(pin, d_full, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(inlier_mask, pin, (size_t)n);
+    } else {
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_track_pnp_path(const vo_ctx *ctx) { return ctx ? ctx->frame_path : 0; }

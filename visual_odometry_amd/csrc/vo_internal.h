@@ -38,9 +38,15 @@ struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    vo_devbuf stage[8];
+    vo_devbuf stage[10];         // 0-7: staging of host-side arguments; 8, 9: vo_track_pnp's block and raw generator draws
     void *pinned = nullptr;      // page-locked host buffer for small read-backs (a copy into pageable memory blocks the caller)
     size_t pinned_cap = 0;
+    // cv::RNG raw outputs that stage[9] holds (vo_track_pnp draws its first samples on the device)
+    uint32_t rng_raw_host[1536];
+    uint64_t rng_raw_seed = 0;
+    const void *rng_raw_dev = nullptr;
+    bool rng_raw_ok = false;
+    int frame_path = 0;          // how the last vo_track_pnp ended (vo_track_pnp_path)
 };
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
@@ -53,6 +59,26 @@ int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out);
 
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
+
+// vo_score.hip: vo_score_pnp on device pointers whose point count (*n_dev <= n_cap) and, optionally, first model
+// (*first_dev; negative: nothing to do) are known only on the device.  Asynchronous.
+int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
+                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks);
+
+// vo_ba.hip: pose refits on device pointers; both enqueue the copy of {pose (6), cost, iterations} into host_out
+// and do not synchronise.  The second starts from [R|t] number sel (or *sel_dev) of dRt, with the number of
+// correspondences optionally on the device (*n_dev <= n).
+int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const uint8_t *dmask, const double *K,
+                         const double *pose_in, int max_iters, double *host_out);
+int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
+                                 const double *K, const double *dRt, int sel, const int *sel_dev, int max_iters, double *host_out);
+
+// vo_ransac.hip: OpenCV's RANSAC loop replayed over the candidates of the first c iterations (one candidate per
+// iteration, valid[i] == 0: none) -> best count, its iteration (-1: none), the loop's iteration bound afterwards.
+void vo_ransac_replay_first_chunk(const int32_t *counts, const uint8_t *valid, int c, int n, int model_points, double conf,
+                                  int max_iters, int *best, int *best_c, int *niters);
+// vo_ransac.hip: advance a cv::RNG state past `iterations` subsets of model_points distinct indices below count.
+int vo_ransac_advance_state(uint64_t *rng_state, int count, int model_points, int iterations);
 
 struct vo_pyr {
     vo_ctx *ctx = nullptr;

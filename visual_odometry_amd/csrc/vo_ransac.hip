@@ -63,7 +63,7 @@ extern "C" int vo_ransac_draw_subsets(uint64_t *rng_state, int count, int model_
 
 // ---------------------------------------------------------------------------
 // Whole RANSAC calls.  One entry point stands in for one cv2 call: all samples are
-// drawn as OpenCV draws them, in chunks (256, 1024, then 4096 at a time); per chunk the
+// drawn as OpenCV draws them, in chunks (256, then up to the loop's current bound); per chunk the
 // GPU solves every minimal problem and scores every candidate against every
 // correspondence (two launches, candidates and points stay on the device), the host
 // reads back one inlier count per candidate and replays OpenCV's sequential loop over
@@ -111,35 +111,32 @@ struct RansacReplay {
     }
 };
 
-// Samples are solved and scored in chunks: 256 first, then four times as many each round (clean data stop the
-// adaptive loop after a handful of iterations; the reference's parking parameters allow 10 000).
-static int ransac_chunk(int round) { return round == 0 ? 256 : round == 1 ? 1024 : 4096; }
-
-// vo_ba.hip: launches the refit and enqueues the copy of {pose (6), cost, iterations} into host_out; no synchronisation
-int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const uint8_t *dmask, const double *K,
-                         const double *pose_in, int max_iters, double *host_out);
-
-static void rotvec_from_matrix(const double *R, double *rv)
+// Samples are solved and scored in chunks: 256 first (clean data stop the adaptive loop after a handful of
+// iterations; the reference's parking parameters allow 10 000), then as many as the loop's current bound still asks
+// for -- the bound only shrinks, so the second chunk normally ends the loop -- at most 4096 per launch.
+static int ransac_chunk(int round, int first, int bound)
 {
-    // via the unit quaternion (largest component first, for accuracy near 0 and pi)
-    const double tr = R[0] + R[4] + R[8];
-    double q[4];   // x, y, z, w
-    if (tr > R[0] && tr > R[4] && tr > R[8]) {
-        q[3] = 1. + tr; q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1];
-    } else if (R[0] >= R[4] && R[0] >= R[8]) {
-        q[0] = 1. + 2. * R[0] - tr; q[1] = R[1] + R[3]; q[2] = R[2] + R[6]; q[3] = R[7] - R[5];
-    } else if (R[4] >= R[8]) {
-        q[1] = 1. + 2. * R[4] - tr; q[0] = R[1] + R[3]; q[2] = R[5] + R[7]; q[3] = R[2] - R[6];
-    } else {
-        q[2] = 1. + 2. * R[8] - tr; q[0] = R[2] + R[6]; q[1] = R[5] + R[7]; q[3] = R[3] - R[1];
-    }
-    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int k = 0; k < 4; ++k) q[k] /= nq;
-    if (q[3] < 0) for (int k = 0; k < 4; ++k) q[k] = -q[k];
-    const double sn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-    const double angle = 2. * atan2(sn, q[3]);
-    const double scale = sn < 1e-12 ? 2. : angle / sn;     // angle / sin(angle / 2) -> 2
-    for (int k = 0; k < 3; ++k) rv[k] = scale * q[k];
+    if (round == 0) return 256;
+    const int want = bound - first < 64 ? 64 : bound - first;
+    return want < 4096 ? want : 4096;
+}
+
+void vo_ransac_replay_first_chunk(const int32_t *counts, const uint8_t *valid, int c, int n, int model_points, double conf,
+                                  int max_iters, int *best, int *best_c, int *niters)
+{
+    RansacReplay loop(max_iters);
+    loop.feed(counts, valid, 1, 0, c, n, model_points, conf);
+    *best = loop.best;
+    *best_c = loop.best_c;
+    *niters = loop.niters;
+}
+
+int vo_ransac_advance_state(uint64_t *rng_state, int count, int model_points, int iterations)
+{
+    if (iterations <= 0) return VO_OK;
+    std::unique_ptr<int32_t[]> scratch(new (std::nothrow) int32_t[(size_t)iterations * model_points]);
+    if (!scratch) { vo_set_error("RANSAC: out of host memory"); return VO_ENOMEM; }
+    return vo_ransac_draw_subsets(rng_state, count, model_points, iterations, nullptr, nullptr, 1, scratch.get());
 }
 
 static void matrix_from_rotvec(const double *rv, double *R)
@@ -199,7 +196,7 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     uint8_t *dvalid = (uint8_t *)(dcounts + S);
     RansacReplay loop(max_iters);
     for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
-        const int c = ransac_chunk(round) < S - first ? ransac_chunk(round) : S - first;
+        const int c = ransac_chunk(round, first, loop.niters) < S - first ? ransac_chunk(round, first, loop.niters) : S - first;
         if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, subsets + (size_t)first * 4))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 4, subsets + (size_t)first * 4, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
         if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub + (size_t)first * 4, c, dRt + (size_t)first * 12, dvalid + first, VO_MEM_DEVICE))) return rc;
@@ -214,11 +211,8 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
         first += c;
     }
     if (rng_state) {     // the generator after the iterations the loop ran, as OpenCV's own loop leaves it
-        const int ran = loop.niters < S ? loop.niters : S;
         uint64_t st = state0;
-        std::unique_ptr<int32_t[]> scratch(new (std::nothrow) int32_t[(size_t)(ran > 0 ? ran : 1) * 4]);
-        if (!scratch) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
-        if (ran > 0 && (rc = vo_ransac_draw_subsets(&st, n, 4, ran, nullptr, nullptr, 1, scratch.get()))) return rc;
+        if ((rc = vo_ransac_advance_state(&st, n, 4, loop.niters < S ? loop.niters : S))) return rc;
         *rng_state = st;
     }
     const int win = loop.best_c;
@@ -227,14 +221,9 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     const int32_t good = loop.best;
     if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)win * 12, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
     const bool refit = good >= 4 && refine_iters > 0;
-    if (refit) {
-        // OpenCV refits with EPnP there; here Gauss-Newton on the same error
-        double R[9], pose[6];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = Rt[4 * r + c];
-        rotvec_from_matrix(R, pose);
-        pose[3] = Rt[3]; pose[4] = Rt[7]; pose[5] = Rt[11];
-        if ((rc = vo_refine_pose_async(ctx, dX, dx, n, dmask, K, pose, refine_iters, refined))) return rc;
-    }
+    // OpenCV refits with EPnP there; here Gauss-Newton on the same error, started from the winner where it lies
+    if (refit && (rc = vo_refine_pose_from_Rt_async(ctx, dX, dx, n, nullptr, dmask, K, dRt, win, nullptr, refine_iters, refined)))
+        return rc;
     if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipMemcpyAsync(pin_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (mem == VO_MEM_HOST) memcpy(inlier_mask, pin_mask, (size_t)n);
@@ -293,7 +282,7 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     VO_HIP_CHECK(hipMemcpyAsync(d2, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     RansacReplay loop(max_iters);
     for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
-        const int c = ransac_chunk(round) < S - first ? ransac_chunk(round) : S - first;
+        const int c = ransac_chunk(round, first, loop.niters) < S - first ? ransac_chunk(round, first, loop.niters) : S - first;
         // the collinearity test of the sampler reads the points on the host
         if ((rc = vo_ransac_draw_subsets(&state, n, 7, c, m1, m2, 10000, subsets + (size_t)first * 7))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28, hipMemcpyHostToDevice, ctx->stream));

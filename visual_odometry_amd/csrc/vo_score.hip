@@ -20,15 +20,24 @@ template <bool PNP>
 __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__restrict__ pa, const float *__restrict__ pb,
                                                               int n, const double *__restrict__ models, int H,
                                                               double fx, double fy, double cx, double cy, float t,
-                                                              int *__restrict__ counts, uint8_t *__restrict__ masks)
+                                                              int *__restrict__ counts, uint8_t *__restrict__ masks,
+                                                              const int *__restrict__ n_dev, const int *__restrict__ first_dev)
 {
+    // n_dev / first_dev (optional): the point count and the index of the first model live on the device, left there
+    // by earlier kernels of the same stream (a negative first model: nothing to score)
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * SC_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (h >= H) return;
+    if (n_dev) n = *n_dev;
+    int64_t first = 0;
+    if (first_dev) {
+        first = *first_dev;
+        if (first < 0) return;
+    }
     constexpr int MS = PNP ? 12 : 9;
     double m[MS];
 #pragma unroll
-    for (int k = 0; k < MS; ++k) m[k] = models[(int64_t)h * MS + k];
+    for (int k = 0; k < MS; ++k) m[k] = models[(first + h) * MS + k];
     const int i0 = blockIdx.y * SC_CHUNK;
     const int i1 = min(n, i0 + SC_CHUNK);
     int good = 0;
@@ -111,7 +120,7 @@ static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, co
     if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(d_c, 0, (size_t)H * 4, ctx->stream));
     dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
     hipLaunchKernelGGL(score_kernel<PNP>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, d_pa, d_pb, n, d_m, H, Kh[0], Kh[4],
-                       Kh[2], Kh[5], t, d_c, d_k);
+                       Kh[2], Kh[5], t, d_c, d_k, (const int *)nullptr, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_HIP_CHECK(hipMemcpyAsync(counts, d_c, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -131,4 +140,22 @@ extern "C" int vo_score_pnp(vo_ctx *ctx, const float *X, const float *x, int n, 
                             int H, double thr, int32_t *counts, uint8_t *masks, int mem)
 {
     return score_common<true>(ctx, X, x, n, Rt, H, K, thr, counts, masks, mem, "vo_score_pnp");
+}
+
+// vo_score_pnp on device pointers whose point count (and, optionally, first model) is only known on the device:
+// n_cap bounds the count for the launch geometry, *n_dev is the count, models + 12 * *first_dev the first model.
+// Asynchronous on the context's stream.
+int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
+                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks)
+{
+    if (H == 0) return VO_OK;
+    const int chunks = n_cap > 0 ? (n_cap + SC_CHUNK - 1) / SC_CHUNK : 1;
+    VO_REQUIRE(chunks <= 65535, "vo_score_pnp: n=%d exceeds %d points", n_cap, 65535 * SC_CHUNK);
+    if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)H * 4, ctx->stream));
+    const float t = (float)(thr * thr);
+    dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
+    hipLaunchKernelGGL(score_kernel<true>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, dX, dx, n_cap, dRt, H, K[0], K[4], K[2],
+                       K[5], t, dcounts, dmasks, n_dev, first_dev);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
 }

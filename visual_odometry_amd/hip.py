@@ -848,6 +848,55 @@ def solve_pnp_ransac(ctx: Context, X, x, K, thr: float, conf: float, max_iters: 
     return (Rt if good.value > 0 else None), mask, int(good.value), int(state.value)
 
 
+def track_pnp(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, landmarks, K, thr: float, conf: float, max_iters: int,
+              refine_iters: int = 10, klt_max_iters: int = 10, klt_eps: float = 0.001, klt_min_eig: float = 1e-2,
+              rng_state: Optional[int] = None):
+    """One tracked frame in one call: klt_track from prev to nxt, the status == 1 filter and solve_pnp_ransac on the
+    survivors, with one synchronisation.  pts (n,2), landmarks (n,3), row for row; pyramids of one image each ->
+    (next_pts (n,2) f32, status (n,) u8, Rt (3,4) f64 or None, inlier mask (n,) u8 over the input rows,
+    number of tracked rows, number of inliers, rng state after the draws).  numpy or torch, as the points are."""
+    Kh = _k_host(K)
+    prm = KltParams(int(klt_max_iters), float(klt_eps), float(klt_min_eig))
+    if prev.batch != 1 or nxt.batch != 1:
+        raise ValueError("track_pnp: pyramids of one image each")
+    if _is_torch(pts):
+        import torch
+        p = _device_points(pts, 1, "track_pnp: pts")[0]
+        X = landmarks
+        if not (_is_torch(X) and X.is_cuda and X.dtype == torch.float32):
+            raise ValueError("track_pnp: landmarks must be a float32 GPU tensor like pts")
+        X = X.reshape(-1, 3).contiguous()
+        n = int(p.shape[0])
+        out = torch.empty_like(p)
+        st = torch.empty(n, dtype=torch.uint8, device=p.device)
+        mask = torch.zeros(n, dtype=torch.uint8, device=p.device)
+        mem = VO_MEM_DEVICE
+    else:
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        X = np.ascontiguousarray(landmarks, np.float32).reshape(-1, 3)
+        n = int(p.shape[0])
+        out = np.zeros_like(p)
+        st = np.zeros(n, np.uint8)
+        mask = np.zeros(n, np.uint8)
+        mem = VO_MEM_HOST
+    if int(X.shape[0]) != n:
+        raise ValueError("track_pnp: pts and landmarks differ in length")
+    state = ctypes.c_uint64(0xFFFFFFFFFFFFFFFF if rng_state is None else rng_state)
+    Rt = np.zeros((3, 4))
+    tracked, good = ctypes.c_int32(), ctypes.c_int32()
+    check(ctx.lib.vo_track_pnp(ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(X), n, ctypes.byref(prm),
+                               Kh.ctypes.data_as(_lib.c_f64p), float(thr), float(conf), int(max_iters), int(refine_iters),
+                               ctypes.byref(state), _ptr(out), _ptr(st), Rt.ctypes.data_as(_lib.c_f64p), _ptr(mask),
+                               ctypes.byref(tracked), ctypes.byref(good), mem), "vo_track_pnp")
+    return out, st, (Rt if good.value > 0 else None), mask, int(tracked.value), int(good.value), int(state.value)
+
+
+def track_pnp_path(ctx: Context) -> int:
+    """How the context's last track_pnp ended: 0 no pose sought, 1 on the single synchronisation, 2 more samples
+    were needed, 3 the device-side sampler or replay could not vouch for its result."""
+    return int(ctx.lib.vo_track_pnp_path(ctx.handle))
+
+
 def find_fundamental_ransac(ctx: Context, m1, m2, thr: float, conf: float, max_iters: int, rng_state: Optional[int] = None):
     """Whole fundamental-matrix RANSAC call (7-point candidates, OpenCV's loop replayed, no refit) ->
     (F (3,3) f64 or None, inlier mask (n,) u8, number of inliers, rng state after the draws).  Host arrays."""

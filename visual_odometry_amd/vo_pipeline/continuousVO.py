@@ -99,12 +99,16 @@ class ContinuousVO:
     False (default) is the reference's active code path: every keyframe restarts the scale.  True is
     an opt-in extension: the new translation and landmarks are scaled so that the baseline equals
     the one implied by the tracked pose -- the step the reference carries as commented-out code
-    (continuousVO.py:128-135) -- which keeps one world scale across keyframes."""
+    (continuousVO.py:128-135) -- which keeps one world scale across keyframes.
+
+    fused_step: a tracked frame's KLT, status filter and PnP run as one library call with one
+    synchronisation (PoseEstimation.track_and_pose) instead of the reference's two calls with the filter
+    between them; the results are identical, False takes the two calls."""
 
     def __init__(self, dataset, descriptorType=ExtractorType.SIFT, matcherType=None, useKLT=True,
                  algo_method=AlgoMethod.P3P, max_point_distance: int = 100, frames_to_skip: int = 10,
                  frame_queue_size: int = 1000, rescale_bootstrap: bool = False,
-                 bootstrap_correspondences: str = "sift") -> None:
+                 bootstrap_correspondences: str = "sift", fused_step: bool = True) -> None:
         self.dataset = dataset
         self.descriptor = FeatureExtractor(descriptorType)
         self.matcher = matcherType
@@ -119,6 +123,7 @@ class ContinuousVO:
         self.frames_to_skip = frames_to_skip
         self.rescale_bootstrap = rescale_bootstrap
         self.bootstrap_correspondences = bootstrap_correspondences
+        self.fused_step = fused_step
         self.keypoint_trajectories = KeypointTrajectories()
         self.frame_idx = 0
         self.bootstrap_idx: List[int] = []
@@ -182,11 +187,20 @@ class ContinuousVO:
         prev_keypoints, prev_trajectories, prev_landmarks = store.at_frame(store.latest_frame)
 
         # the queue's images are never written to: the pyramid built for prev_img one step ago is kept
-        tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints, reuse_pyramids=True)
+        T = None
+        if self.fused_step:
+            # tracker, filter and PnP in one library call; a frame with too few survivors (or no pose) falls
+            # through to the forced bootstrap exactly as below
+            tracked_pts, status, T, inliers = self.poseEstimator.track_and_pose(prev_img, img, prev_keypoints, prev_landmarks,
+                                                                                reuse_pyramids=True)
+        else:
+            tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints, reuse_pyramids=True)
         tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
                                                                       prev_trajectories)
         if tracked_landmarks.shape[0] > 5:
-            T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
+            if not self.fused_step:
+                T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
+            assert T is not None, "PNP RANSAC was not able to compute a pose from 2D - 3D correspondences"
             ratio = inlier_ratio(inliers, self.inlier_count)
         else:
             warnings.warn("too few points, forced bootstrap")
