@@ -311,7 +311,10 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, in
  * (continuousVO.py:168-172) and cv.solvePnPRansac with its refit on the survivors
  * (poseEstimation.py:51-77) -- with one synchronisation instead of the three round trips of the separate
  * calls.  The outcome is that of vo_klt_track (init_pts = NULL) followed by vo_solve_pnp_ransac on the rows
- * with status 1, in their order.  prev / next: built pyramids of one image each.  prev_pts (n,2) float32 and
+ * with status 1, in their order.  prev / next: pyramids of one image each; prev built, next built or -- when
+ * next_image is given (one grayscale uint8 image with row pitch next_row_stride, following `mem`) -- built from
+ * it here first, as vo_pyr_build would, with the upload of a host image sharing the page-locked copy of the
+ * points instead of waiting for the device on its own.  prev_pts (n,2) float32 and
  * landmarks (n,3) float32, row i of one belonging to row i of the other; next_pts (n,2) float32, status (n)
  * uint8 as vo_klt_track returns them; inlier_mask (n) uint8 over the INPUT rows (0 for rows that were not
  * tracked); all five follow `mem`.  *n_tracked (host) = rows with status 1, *n_inliers (host) = 0 when no pose
@@ -319,8 +322,8 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const float *m2, in
  * then left untouched.  K, thr, conf, max_iters, refine_iters, rng_state as in vo_solve_pnp_ransac.  Always
  * synchronises the stream (the pose returns to the host).
  */
-int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
-                 int n, const vo_klt_params *params, const double *K, double thr, double conf, int max_iters,
+int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const uint8_t *next_image, int64_t next_row_stride,
+                 const float *prev_pts, const float *landmarks, int n, const vo_klt_params *params, const double *K, double thr, double conf, int max_iters,
                  int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
                  uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int mem);
 /* How the context's last vo_track_pnp call ended (no counterpart in the reference; for tests and profiling):

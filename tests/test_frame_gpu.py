@@ -54,6 +54,16 @@ def _check(hip, ctx, img0, img1, pts, X, thr=1.0, conf=0.999, iters=2000):
     else:
         np.testing.assert_array_equal(got[2], ref[2])
     assert got[6] == ref[6]
+    # the new frame's pyramid built inside the call from the image
+    p2 = hip.Pyramid(ctx, 1, h, w, 3)
+    inside = hip.track_pnp(ctx, p0, p2, pts, X, K, thr, conf, iters, next_image=img1)
+    for a, b in zip(inside, got):
+        if a is None or b is None:
+            assert a is None and b is None
+        else:
+            np.testing.assert_array_equal(a, b)
+    for lvl in range(p1.max_level + 1):
+        np.testing.assert_array_equal(p2.download(0, lvl), p1.download(0, lvl))
     return got, (p0, p1)
 
 
@@ -123,6 +133,11 @@ def test_device_resident_points(ctx):
         img0, img1, pts, X, R, t = _scene(seed=11, n=700, outlier_frac=outliers)
         got, (p0, p1) = _check(hip, ctx, img0, img1, pts, X)
         dev = hip.track_pnp(ctx, p0, p1, torch.from_numpy(pts).cuda(), torch.from_numpy(X).cuda(), K, 1.0, 0.999, 2000)
+        p2 = hip.Pyramid(ctx, 1, img1.shape[0], img1.shape[1], 3)
+        dev2 = hip.track_pnp(ctx, p0, p2, torch.from_numpy(pts).cuda(), torch.from_numpy(X).cuda(), K, 1.0, 0.999, 2000,
+                             next_image=torch.from_numpy(img1).cuda())
+        np.testing.assert_array_equal(dev2[0].cpu().numpy(), got[0])
+        np.testing.assert_array_equal(dev2[3].cpu().numpy(), got[3])
         np.testing.assert_array_equal(dev[0].cpu().numpy(), got[0])
         np.testing.assert_array_equal(dev[1].cpu().numpy(), got[1])
         np.testing.assert_array_equal(dev[3].cpu().numpy(), got[3])

@@ -560,12 +560,14 @@ __device__ static void rotvec_of_Rt(const double *Rt, double *rv)
 
 // Start pose: `start` (rotation vector, translation), or -- when Rt_src is given -- the [R|t] at
 // Rt_src + 12 * (sel_dev ? *sel_dev : sel), converted on the device (a negative index: nothing to refine, NaN out).
-// n_dev (optional): the number of correspondences lives on the device.
+// n_dev (optional): the number of correspondences lives on the device.  mask_row (optional): correspondence i is
+// selected by mask[mask_row[i]] instead of mask[i].
 __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float *__restrict__ X, const float *__restrict__ x,
                                                                      const uint8_t *__restrict__ mask, int n, BaK K, Pose6 start,
                                                                      int max_iters, double *__restrict__ out,
                                                                      const double *__restrict__ Rt_src, int sel,
-                                                                     const int *__restrict__ sel_dev, const int *__restrict__ n_dev)
+                                                                     const int *__restrict__ sel_dev, const int *__restrict__ n_dev,
+                                                                     const int *__restrict__ mask_row)
 {
     __shared__ double red[REFINE_THREADS / 64][28];
     __shared__ double tot[28];
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = 0;
         for (int i = tid; i < n; i += REFINE_THREADS) {
-            if (mask && !mask[i]) continue;
+            if (mask && !mask[mask_row ? mask_row[i] : i]) continue;
             const double Xd[3] = {(double)X[3 * (int64_t)i], (double)X[3 * (int64_t)i + 1], (double)X[3 * (int64_t)i + 2]};
             const double ob[2] = {(double)x[2 * (int64_t)i], (double)x[2 * (int64_t)i + 1]};
             double rr[2], Jc[12], Jp[6];
@@ -726,29 +728,35 @@ int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, c
     if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
     double *d_out = (double *)p;
     hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
-                       (const double *)nullptr, 0, (const int *)nullptr, (const int *)nullptr);
+                       (const double *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;
 }
 
 // The refit started from a candidate that lives on the device: [R|t] number sel (or *sel_dev) of dRt; the number of
-// correspondences may live on the device too (n_dev, bounded by n).  Enqueues the copy of {pose (6), cost,
-// iterations} into host_out (page-locked); no synchronisation.
+// correspondences may live on the device too (n_dev, bounded by n); correspondence i is selected by
+// dmask[mask_row ? mask_row[i] : i].  {pose (6), cost, iterations} go to d_out when given (8 doubles on the device,
+// left there for the caller to fetch), else through a context buffer into host_out (page-locked) with the copy
+// enqueued here; no synchronisation.
 int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
-                                 const double *K, const double *dRt, int sel, const int *sel_dev, int max_iters, double *host_out)
+                                 const int *mask_row, const double *K, const double *dRt, int sel, const int *sel_dev,
+                                 int max_iters, double *host_out, double *d_out)
 {
     BaK Kv;
     memcpy(Kv.k, K, sizeof(Kv.k));
     Pose6 start = {};
     int rc;
     void *p;
-    if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
-    double *d_out = (double *)p;
+    const bool own = d_out == nullptr;
+    if (own) {
+        if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
+        d_out = (double *)p;
+    }
     hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
-                       dRt, sel, sel_dev, n_dev);
+                       dRt, sel, sel_dev, n_dev, mask_row);
     VO_HIP_CHECK(hipGetLastError());
-    VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (own) VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;
 }
 

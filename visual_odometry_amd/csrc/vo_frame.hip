@@ -7,8 +7,9 @@
 // back to be filtered, the sampler needs the number of survivors, the RANSAC loop reads the inlier counts.  Here
 // the survivors are compacted on the device, the first 256 samples are drawn on the device from the generator's
 // raw output (which does not depend on the point count; only the modulus and the rejections do), the loop over
-// their inlier counts is replayed by one wavefront, and the winner's mask and refit are launched on an index that
-// still lives on the device.  The host reads everything back once, replays the loop itself on the returned counts
+// their inlier counts is replayed by the kernel that writes the winner's mask, and the refit is launched on an index
+// that still lives on the device.  Seven launches after the pyramid (tracker, preparation, P3P, scoring, mask, refit)
+// with one copy in and one copy out.  The host reads everything back once, replays the loop itself on the returned counts
 // (its own libm decides the adaptive bound) and, when the loop needs more than the first chunk, when the device's
 // replay disagrees, or when the raw draws ran out, finishes with vo_solve_pnp_ransac on the compacted points.
 // Either way the outcome is that of vo_klt_track followed by vo_solve_pnp_ransac on the rows with status 1.
@@ -30,44 +31,6 @@ struct FrameMeta {
     double Rt[12];    // the winner
 };
 
-// Rows with status 1, in order: landmarks and tracked points side by side.  One workgroup.
-__global__ __launch_bounds__(FS_THREADS) void frame_compact_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
-                                                                   const float *__restrict__ pts, int n, float *__restrict__ Xc,
-                                                                   float *__restrict__ xc, FrameMeta *__restrict__ meta)
-{
-    __shared__ int wcount[FS_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
-        const int i = i0 + tid;
-        const bool keep = i < n && status[i] == 1;
-        const unsigned long long b = __ballot(keep);
-        if (lane == 0) wcount[wv] = __popcll(b);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < FS_THREADS / 64; ++w) {
-            const int c = wcount[w];
-            before += w < wv ? c : 0;
-            total += c;
-        }
-        if (keep) {
-            const int64_t j = base + before + __popcll(b & ((1ull << lane) - 1));
-            Xc[3 * j] = X[3 * (int64_t)i]; Xc[3 * j + 1] = X[3 * (int64_t)i + 1]; Xc[3 * j + 2] = X[3 * (int64_t)i + 2];
-            xc[2 * j] = pts[2 * (int64_t)i]; xc[2 * j + 1] = pts[2 * (int64_t)i + 1];
-        }
-        base += total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        meta->m = base;
-        meta->win = -1;
-        meta->best = 0;
-        meta->niters = 0;
-        meta->overflow = 0;
-    }
-}
-
 // One subset of four distinct indices drawn from position p of the raw generator output, as
 // RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another draw.
 // Returns the position after the subset; FS_DRAWS when the draws ran out (a subset whose last draw is the
@@ -84,23 +47,62 @@ __device__ static inline int frame_draw_subset(const uint32_t *raw, int p, uint3
     return have == 4 && p < FS_DRAWS ? p : FS_DRAWS;
 }
 
-// Subsets 0 .. c0-1.  Where subset i starts depends on the rejections before it; "the position after the subset
-// that starts at p" is a function of p alone, so the starts are the orbit of 0 under it: every position computes its
-// successor, log2(c0) rounds of pointer doubling give hops of 1, 2, 4, ... subsets, and sample i combines the hops of
-// its set bits.  One workgroup.
-__global__ __launch_bounds__(FS_THREADS) void frame_sample_kernel(const uint32_t *__restrict__ raw_g, FrameMeta *__restrict__ meta,
-                                                                  int c0, int *__restrict__ subsets)
+// Everything between the tracker and the minimal solver, in one workgroup:
+//  * rows with status 1 are compacted in order (landmarks and tracked points side by side; orig[j] = input row of
+//    survivor j), the full-length inlier mask and the candidates' inlier counts are cleared;
+//  * subsets 0 .. c0-1 are drawn.  Where subset i starts depends on the rejections before it; "the position after
+//    the subset that starts at p" is a function of p alone, so the starts are the orbit of 0 under it: every position
+//    computes its successor, log2(c0) rounds of pointer doubling give hops of 1, 2, 4, ... subsets, and sample i
+//    combines the hops of its set bits.
+__global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
+                                                                const float *__restrict__ pts, int n,
+                                                                const uint32_t *__restrict__ raw_g, int c0, float *__restrict__ Xc,
+                                                                float *__restrict__ xc, int *__restrict__ orig,
+                                                                FrameMeta *__restrict__ meta, int *__restrict__ counts,
+                                                                uint8_t *__restrict__ full, int *__restrict__ subsets)
 {
+    __shared__ int wcount[FS_THREADS / 64];
     __shared__ uint32_t raw[FS_DRAWS];
     __shared__ unsigned short hop[2][FS_DRAWS + 1];
-    const int tid = threadIdx.x;
-    const int m = meta->m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = raw_g[p];
+    if (tid <= c0) counts[tid] = 0;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
+        const int i = i0 + tid;
+        const bool keep = i < n && status[i] == 1;
+        if (i < n) full[i] = 0;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wcount[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < FS_THREADS / 64; ++w) {
+            const int c = wcount[w];
+            before += w < wv ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const int64_t j = base + before + __popcll(b & ((1ull << lane) - 1));
+            Xc[3 * j] = X[3 * (int64_t)i]; Xc[3 * j + 1] = X[3 * (int64_t)i + 1]; Xc[3 * j + 2] = X[3 * (int64_t)i + 2];
+            xc[2 * j] = pts[2 * (int64_t)i]; xc[2 * j + 1] = pts[2 * (int64_t)i + 1];
+            orig[j] = i;
+        }
+        base += total;
+        __syncthreads();
+    }
+    const int m = base;
+    if (tid == 0) {
+        meta->m = m;
+        meta->win = -1;
+        meta->best = 0;
+        meta->niters = 0;
+        meta->overflow = 0;
+    }
     if (m < 4) {
         if (tid < c0) { subsets[4 * tid] = 0; subsets[4 * tid + 1] = 0; subsets[4 * tid + 2] = 0; subsets[4 * tid + 3] = 0; }
         return;
     }
-    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = raw_g[p];
-    __syncthreads();
     int idx[4];
     for (int p = tid; p < FS_DRAWS; p += FS_THREADS) hop[0][p] = (unsigned short)frame_draw_subset(raw, p, (uint32_t)m, idx);
     if (tid == 0) { hop[0][FS_DRAWS] = FS_DRAWS; hop[1][FS_DRAWS] = FS_DRAWS; }
@@ -136,14 +138,21 @@ __device__ static int frame_update_num_iters(double p, double ep, int model_poin
     return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)lrint(num / denom);
 }
 
-// OpenCV's sequential loop over the first chunk's candidates, by one wavefront: candidate c improves the best when
-// its count exceeds max(best, 3) and c is still below the iteration bound, which every improvement recomputes.
-// Only improvements change the state, so per 64 candidates the wavefront jumps from one improvement to the next.
-__global__ __launch_bounds__(64) void frame_replay_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid, int c0,
-                                                          int max_iters, double conf, const double *__restrict__ Rt,
-                                                          FrameMeta *__restrict__ meta)
+// The winner of the first chunk and its inlier mask.  Every wavefront replays OpenCV's sequential loop over the
+// chunk's candidates for itself (candidate c improves the best when its count exceeds max(best, 3) and c is still
+// below the iteration bound, which every improvement recomputes; only improvements change the state, so per 64
+// candidates the wavefront jumps from one improvement to the next), then scores its share of the survivors against
+// the winner with the expression of the scoring kernel and writes the mask at the survivors' input rows.
+#define FM_WAVES 4
+#define FM_POINTS 1024      // survivors per workgroup
+__global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid,
+                                                                   int c0, int max_iters, double conf, const double *__restrict__ Rt,
+                                                                   const float *__restrict__ Xc, const float *__restrict__ xc,
+                                                                   const int *__restrict__ orig, double fx, double fy, double cx,
+                                                                   double cy, float t, FrameMeta *__restrict__ meta,
+                                                                   uint8_t *__restrict__ full)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = meta->m;
     int niters = max_iters, best = -1, best_c = -1;
     bool stop = m < 4;
@@ -161,48 +170,28 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(const int *__restrict_
             niters = frame_update_num_iters(conf, (double)(m - best) / m, 4, niters);
         }
     }
-    if (lane == 0) {
-        meta->win = best_c;
-        meta->best = best_c >= 0 ? best : 0;
-        meta->niters = niters;
-    }
-    if (best_c >= 0 && lane < 12) meta->Rt[lane] = Rt[12 * (int64_t)best_c + lane];
-}
-
-// rank[i] = row of correspondence i among the survivors, -1 for the others (the compaction's inverse)
-__global__ __launch_bounds__(FS_THREADS) void frame_rank_kernel(const uint8_t *__restrict__ status, int n, int *__restrict__ rank)
-{
-    __shared__ int wcount[FS_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
-        const int i = i0 + tid;
-        const bool keep = i < n && status[i] == 1;
-        const unsigned long long b = __ballot(keep);
-        if (lane == 0) wcount[wv] = __popcll(b);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < FS_THREADS / 64; ++w) {
-            const int c = wcount[w];
-            before += w < wv ? c : 0;
-            total += c;
+    if (blockIdx.x == 0 && wv == 0) {
+        if (lane == 0) {
+            meta->win = best_c;
+            meta->best = best_c >= 0 ? best : 0;
+            meta->niters = niters;
         }
-        if (i < n) rank[i] = keep ? base + before + __popcll(b & ((1ull << lane) - 1)) : -1;
-        base += total;
-        __syncthreads();
+        if (best_c >= 0 && lane < 12) meta->Rt[lane] = Rt[12 * (int64_t)best_c + lane];
     }
+    if (best_c < 0) return;
+    double mdl[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) mdl[k] = Rt[12 * (int64_t)best_c + k];
+    const int i0 = blockIdx.x * FM_POINTS + wv * (FM_POINTS / FM_WAVES);
+    const int i1 = min(m, i0 + FM_POINTS / FM_WAVES);
+    for (int i = i0 + lane; i < i1; i += 64) full[orig[i]] = vo_pnp_inlier(mdl, Xc, xc, i, fx, fy, cx, cy, t) ? 1 : 0;
 }
 
-// The survivors' inlier mask spread back over all correspondences; zero when there is no winner.
-__global__ void frame_expand_kernel(const int *__restrict__ rank, const uint8_t *__restrict__ mask_c, int n,
-                                    const FrameMeta *__restrict__ meta, int use_meta, uint8_t *__restrict__ mask)
+// mask[orig[j]] = mask_c[j] for the m survivors (the long path's mask comes in survivor order)
+__global__ void frame_scatter_kernel(const int *__restrict__ orig, const uint8_t *__restrict__ mask_c, int m, uint8_t *__restrict__ full)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool none = use_meta && meta->win < 0;
-    const int j = rank[i];
-    mask[i] = (!none && j >= 0) ? mask_c[j] : 0;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) full[orig[j]] = mask_c[j];
 }
 
 // cv::RNG raw outputs from `state` on (multiply-with-carry), FS_DRAWS of them, kept on the device per context
@@ -236,8 +225,8 @@ static void frame_matrix_from_rotvec(const double *rv, double *R)
     R[6] = v * kx * kz - s * ky; R[7] = v * ky * kz + s * kx; R[8] = c + v * kz * kz;
 }
 
-extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
-                            int n, const vo_klt_params *klt, const double *K, double thr, double conf, int max_iters,
+extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const uint8_t *next_image, int64_t next_row_stride,
+                            const float *prev_pts, const float *landmarks, int n, const vo_klt_params *klt, const double *K, double thr, double conf, int max_iters,
                             int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
                             uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int mem)
 {
@@ -249,21 +238,29 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
     *n_tracked = 0;
     *n_inliers = 0;
     ctx->frame_path = 0;
-    if (n == 0) return VO_OK;
     VO_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (next_image) return vo_pyr_build(ctx, next, next_image, next_row_stride, 0, mem);
+        return VO_OK;
+    }
     const int c0 = max_iters < FS_SAMPLES ? max_iters : FS_SAMPLES;
     const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
     int rc;
     const uint32_t *d_raw;
     if ((rc = frame_raw_draws(ctx, state0, &d_raw))) return rc;
-    // one device block for everything that stays on the device between the steps
+    const bool host = mem == VO_MEM_HOST;
+    // One device block: [inputs | work | outputs].  Inputs and outputs are contiguous so that one copy brings the
+    // host's arrays in and one takes everything the host reads back out (page-locked on the host side).
     size_t off = 0;
     auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const bool host = mem == VO_MEM_HOST;
-    const size_t o_pts = take(host ? (size_t)n * 8 : 0), o_X = take(host ? (size_t)n * 12 : 0), o_next = take(host ? (size_t)n * 8 : 0),
-                 o_status = take(host ? (size_t)n : 0), o_full = take(host ? (size_t)n : 0), o_Xc = take((size_t)n * 12),
-                 o_xc = take((size_t)n * 8), o_rank = take((size_t)n * 4), o_maskc = take((size_t)n), o_meta = take(sizeof(FrameMeta)),
-                 o_sub = take((size_t)c0 * 16), o_Rt = take((size_t)c0 * 96), o_counts = take((size_t)c0 * 4 + 16), o_valid = take((size_t)c0);
+    const size_t o_pts = take(host ? (size_t)n * 8 : 0), o_X = take(host ? (size_t)n * 12 : 0), in_bytes = off;
+    const size_t o_Xc = take((size_t)n * 12), o_xc = take((size_t)n * 8), o_orig = take((size_t)n * 4), o_maskc = take((size_t)n),
+                 o_sub = take((size_t)c0 * 16), o_Rt = take((size_t)c0 * 96);
+    const size_t out0 = off;
+    const size_t o_meta = take(sizeof(FrameMeta)), o_ref = take(64), o_counts = take((size_t)c0 * 4 + 4), o_valid = take((size_t)c0);
+    const size_t head_bytes = off - out0;
+    const size_t o_next = take(host ? (size_t)n * 8 : 0), o_status = take(host ? (size_t)n : 0), o_full = take(host ? (size_t)n : 0);
+    const size_t out_bytes = off - out0;
     void *blk;
     if ((rc = vo_stage_reserve(ctx, 8, off, &blk))) return rc;
     char *base = (char *)blk;
@@ -273,69 +270,60 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
     uint8_t *d_status = host ? (uint8_t *)(base + o_status) : status;
     uint8_t *d_full = host ? (uint8_t *)(base + o_full) : inlier_mask;
     float *d_Xc = (float *)(base + o_Xc), *d_xc = (float *)(base + o_xc);
-    int *d_rank = (int *)(base + o_rank), *d_sub = (int *)(base + o_sub), *d_counts = (int *)(base + o_counts);
+    int *d_orig = (int *)(base + o_orig), *d_sub = (int *)(base + o_sub), *d_counts = (int *)(base + o_counts);
     uint8_t *d_maskc = (uint8_t *)(base + o_maskc), *d_valid = (uint8_t *)(base + o_valid);
     FrameMeta *d_meta = (FrameMeta *)(base + o_meta);
-    double *d_Rt = (double *)(base + o_Rt);
-    // page-locked read-back area
-    size_t poff = 0;
-    auto ptake = [&poff](size_t bytes) { const size_t o = poff; poff += (bytes + 63) & ~(size_t)63; return o; };
-    const size_t p_next = ptake(host ? (size_t)n * 8 : 0), p_status = ptake(host ? (size_t)n : 0), p_full = ptake(host ? (size_t)n : 0),
-                 p_meta = ptake(sizeof(FrameMeta)), p_counts = ptake((size_t)c0 * 4), p_valid = ptake((size_t)c0), p_ref = ptake(64);
+    double *d_Rt = (double *)(base + o_Rt), *d_ref = (double *)(base + o_ref);
+    const size_t img_bytes = host && next_image ? (((size_t)next->w[0] * next->h[0] + 255) & ~(size_t)255) : 0;
     void *pin;
-    if ((rc = vo_pinned_reserve(ctx, poff, &pin))) return rc;
-    char *hp = (char *)pin;
-    FrameMeta *h_meta = (FrameMeta *)(hp + p_meta);
-    double *h_ref = (double *)(hp + p_ref);
-    for (int k = 0; k < 8; ++k) h_ref[k] = NAN;
+    if ((rc = vo_pinned_reserve(ctx, img_bytes + in_bytes + out_bytes, &pin))) return rc;
+    char *hin = (char *)pin + img_bytes, *hout = hin + in_bytes;       // hout mirrors base + out0
+    const FrameMeta *h_meta = (const FrameMeta *)(hout + (o_meta - out0));
+    const double *h_ref = (const double *)(hout + (o_ref - out0));
 
-    if (host) VO_HIP_CHECK(hipMemcpyAsync((void *)d_pts, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    // the new frame's pyramid first: its upload and the points' share the page-locked buffer, nothing waits
+    if (next_image) {
+        if (host) rc = vo_pyr_build_pinned(ctx, next, next_image, next_row_stride, (uint8_t *)pin);
+        else rc = vo_pyr_build(ctx, next, next_image, next_row_stride, 0, VO_MEM_DEVICE);
+        if (rc) return rc;
+    }
+    if (host) {
+        memcpy(hin + o_pts, prev_pts, (size_t)n * 8);
+        memcpy(hin + o_X, landmarks, (size_t)n * 12);
+        VO_HIP_CHECK(hipMemcpyAsync(base, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
-    // the landmarks are staged while the tracker runs
-    if (host) VO_HIP_CHECK(hipMemcpyAsync((void *)d_X, landmarks, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(frame_compact_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_Xc, d_xc, d_meta);
-    hipLaunchKernelGGL(frame_rank_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, n, d_rank);
+    hipLaunchKernelGGL(frame_prep_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_raw, c0, d_Xc, d_xc,
+                       d_orig, d_meta, d_counts, d_full, d_sub);
     VO_HIP_CHECK(hipGetLastError());
     if (n >= 4) {
-        hipLaunchKernelGGL(frame_sample_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_raw, d_meta, c0, d_sub);
-        VO_HIP_CHECK(hipGetLastError());
         if ((rc = vo_p3p_solve(ctx, d_Xc, d_xc, n, K, d_sub, c0, d_Rt, d_valid, VO_MEM_DEVICE))) return rc;
-        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c0, nullptr, thr, d_counts, nullptr))) return rc;
-        hipLaunchKernelGGL(frame_replay_kernel, dim3(1), dim3(64), 0, ctx->stream, d_counts, d_valid, c0, max_iters, conf, d_Rt, d_meta);
+        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c0, nullptr, thr, d_counts, nullptr, true))) return rc;
+        hipLaunchKernelGGL(frame_mask_kernel, dim3((n + FM_POINTS - 1) / FM_POINTS), dim3(64 * FM_WAVES), 0, ctx->stream, d_counts,
+                           d_valid, c0, max_iters, conf, d_Rt, d_Xc, d_xc, d_orig, K[0], K[4], K[2], K[5], (float)(thr * thr), d_meta,
+                           d_full);
         VO_HIP_CHECK(hipGetLastError());
-        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, 1, &d_meta->win, thr, d_counts + c0, d_maskc))) return rc;
-        if (refine_iters > 0 &&
-            (rc = vo_refine_pose_from_Rt_async(ctx, d_Xc, d_xc, n, &d_meta->m, d_maskc, K, d_Rt, 0, &d_meta->win, refine_iters, h_ref)))
+        if (refine_iters > 0 && (rc = vo_refine_pose_from_Rt_async(ctx, d_Xc, d_xc, n, &d_meta->m, d_full, d_orig, K, d_Rt, 0,
+                                                                   &d_meta->win, refine_iters, nullptr, d_ref)))
             return rc;
-        hipLaunchKernelGGL(frame_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_rank, d_maskc, n, d_meta, 1, d_full);
-        VO_HIP_CHECK(hipGetLastError());
-        VO_HIP_CHECK(hipMemcpyAsync(hp + p_counts, d_counts, (size_t)c0 * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(hp + p_valid, d_valid, (size_t)c0, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream));
     }
-    VO_HIP_CHECK(hipMemcpyAsync(h_meta, d_meta, sizeof(FrameMeta), hipMemcpyDeviceToHost, ctx->stream));
-    if (host) {
-        VO_HIP_CHECK(hipMemcpyAsync(hp + p_next, d_next, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(hp + p_status, d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(hp + p_full, d_full, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    VO_HIP_CHECK(hipMemcpyAsync(hout, base + out0, host ? out_bytes : head_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const FrameMeta meta = *h_meta;
     const int m = meta.m;
     *n_tracked = m;
     if (host) {
-        memcpy(next_pts, hp + p_next, (size_t)n * 8);
-        memcpy(status, hp + p_status, (size_t)n);
+        memcpy(next_pts, hout + (o_next - out0), (size_t)n * 8);
+        memcpy(status, hout + (o_status - out0), (size_t)n);
     }
     if (m < 4 || n < 4) {
-        if (host) memset(inlier_mask, 0, (size_t)n);
-        else if (n >= 4) { VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream)); VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+        if (host) memset(inlier_mask, 0, (size_t)n);      // a device-side mask was cleared by the preparation kernel
         return VO_OK;
     }
     // the host's own replay of the loop decides (its libm computes the adaptive bound OpenCV's would)
     int hb, hbc, hn;
-    vo_ransac_replay_first_chunk((const int32_t *)(hp + p_counts), (const uint8_t *)(hp + p_valid), c0, m, 4, conf, max_iters, &hb, &hbc, &hn);
+    vo_ransac_replay_first_chunk((const int32_t *)(hout + (o_counts - out0)), (const uint8_t *)(hout + (o_valid - out0)), c0, m, 4, conf,
+                                 max_iters, &hb, &hbc, &hn);
     const bool finished = hn <= c0 || c0 >= max_iters;
     const bool agree = !meta.overflow && hbc == meta.win && hn == meta.niters && (hbc < 0 || hb == meta.best);
     if (finished && agree) {
@@ -346,7 +334,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
         }
         if (hbc < 0) {
             if (host) memset(inlier_mask, 0, (size_t)n);
-            return VO_OK;            // the expand kernel has zeroed a device-side mask
+            return VO_OK;
         }
         double Rt[12];
         memcpy(Rt, meta.Rt, sizeof(Rt));
@@ -360,7 +348,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
             }
         }
         memcpy(Rt_out, Rt, sizeof(Rt));
-        if (host) memcpy(inlier_mask, hp + p_full, (size_t)n);
+        if (host) memcpy(inlier_mask, hout + (o_full - out0), (size_t)n);
         *n_inliers = hb;
         return VO_OK;
     }
@@ -371,13 +359,11 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
     if ((rc = vo_solve_pnp_ransac(ctx, d_Xc, d_xc, m, K, thr, conf, max_iters, refine_iters, rng_state, Rt_out, d_maskc, &good, VO_MEM_DEVICE)))
         return rc;
     *n_inliers = good;
-    if (good == 0) {
-        if (host) memset(inlier_mask, 0, (size_t)n);
-        else { VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream)); VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
-        return VO_OK;
+    VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream));
+    if (good > 0) {
+        hipLaunchKernelGGL(frame_scatter_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d_orig, d_maskc, m, d_full);
+        VO_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(frame_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_rank, d_maskc, n, d_meta, 0, d_full);
-    VO_HIP_CHECK(hipGetLastError());
     if (host) {
         if ((rc = vo_pinned_reserve(ctx, (size_t)n, &pin))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(pin, d_full, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -51,6 +51,25 @@ struct vo_ctx {
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
 
+// Reprojection test of solvePnPRansac's scoring: point i of pa (n,3) under the 3x4 model m against pb (n,2);
+// float64 in this order, the squared error compared in float32 (every kernel that scores PnP candidates uses it,
+// so their masks agree bit for bit).
+__device__ __forceinline__ bool vo_pnp_inlier(const double *m, const float *__restrict__ pa, const float *__restrict__ pb, int64_t i,
+                                              double fx, double fy, double cx, double cy, float t)
+{
+    double Xw = pa[3 * i], Yw = pa[3 * i + 1], Zw = pa[3 * i + 2];
+    double xc = m[0] * Xw + m[1] * Yw + m[2] * Zw + m[3];
+    double yc = m[4] * Xw + m[5] * Yw + m[6] * Zw + m[7];
+    double zc = m[8] * Xw + m[9] * Yw + m[10] * Zw + m[11];
+    zc = zc ? 1. / zc : 1;
+    xc *= zc;
+    yc *= zc;
+    float u = (float)(xc * fx + cx), v = (float)(yc * fy + cy);
+    float du = pb[2 * i] - u, dv = pb[2 * i + 1] - v;
+    float err = du * du + dv * dv;
+    return err <= t;
+}
+
 // Looks up the current device's copy of the fixed scratch array of vo_klt_track_fb_noalloc (vo_klt.hip).
 int vo_klt_noalloc_setup(int device);
 
@@ -61,17 +80,25 @@ int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out);
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
 
 // vo_score.hip: vo_score_pnp on device pointers whose point count (*n_dev <= n_cap) and, optionally, first model
-// (*first_dev; negative: nothing to do) are known only on the device.  Asynchronous.
+// (*first_dev; negative: nothing to do) are known only on the device; counts_cleared: dcounts is already zero.
+// Asynchronous.
 int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
-                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks);
+                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks,
+                     bool counts_cleared);
 
 // vo_ba.hip: pose refits on device pointers; both enqueue the copy of {pose (6), cost, iterations} into host_out
 // and do not synchronise.  The second starts from [R|t] number sel (or *sel_dev) of dRt, with the number of
-// correspondences optionally on the device (*n_dev <= n).
+// correspondences optionally on the device (*n_dev <= n), selecting correspondence i by dmask[mask_row[i]] when
+// mask_row is given, and leaving the result in d_out (device) instead of host_out when d_out is given.
 int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const uint8_t *dmask, const double *K,
                          const double *pose_in, int max_iters, double *host_out);
 int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
-                                 const double *K, const double *dRt, int sel, const int *sel_dev, int max_iters, double *host_out);
+                                 const int *mask_row, const double *K, const double *dRt, int sel, const int *sel_dev,
+                                 int max_iters, double *host_out, double *d_out);
+
+// vo_pyramid.hip: one host image into a one-image pyramid through page-locked memory the caller provides (w * h
+// bytes, untouched until the stream has run the copy); does not wait for the device.
+int vo_pyr_build_pinned(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, uint8_t *pin);
 
 // vo_ransac.hip: OpenCV's RANSAC loop replayed over the candidates of the first c iterations (one candidate per
 // iteration, valid[i] == 0: none) -> best count, its iteration (-1: none), the loop's iteration bound afterwards.

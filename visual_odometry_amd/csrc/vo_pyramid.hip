@@ -207,6 +207,9 @@ extern "C" int vo_pyr_level_shape(const vo_pyr *pyr, int level, int *height, int
     return VO_OK;
 }
 
+static int pyr_own_level0(vo_ctx *ctx, vo_pyr *pyr);
+static int pyr_launch_levels(vo_ctx *ctx, vo_pyr *pyr);
+
 extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem)
 {
     VO_REQUIRE(ctx && pyr && img, "vo_pyr_build: NULL argument");
@@ -220,14 +223,8 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
                (long long)row_stride, pyr->h[0]);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     if (mem == VO_MEM_HOST) {
-        // tight library-owned copy of level 0 (+ slack for 4-byte row reads)
-        size_t need = (size_t)pyr->w[0] * pyr->h[0] * pyr->batch + 256;
-        if (pyr->own0_bytes < need) {
-            if (pyr->own0) { VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); VO_HIP_CHECK(hipFree(pyr->own0)); pyr->own0 = nullptr; }
-            hipError_t e = hipMalloc((void **)&pyr->own0, need);
-            if (e != hipSuccess) { vo_set_error("vo_pyr_build: device allocation of %zu bytes failed", need); return VO_ENOMEM; }
-            pyr->own0_bytes = need;
-        }
+        int rc = pyr_own_level0(ctx, pyr);
+        if (rc) return rc;
         const size_t img_bytes = (size_t)pyr->w[0] * pyr->h[0];
         if (row_stride == pyr->w[0] && (pyr->batch == 1 || img_stride == (int64_t)img_bytes)) {
             // tight input: one linear copy (2-D copies from pageable memory go row by row)
@@ -237,14 +234,51 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
                 VO_HIP_CHECK(hipMemcpy2DAsync(pyr->own0 + b * img_bytes, pyr->w[0], img + (size_t)b * img_stride, row_stride,
                                               pyr->w[0], pyr->h[0], hipMemcpyHostToDevice, ctx->stream));
         }
-        pyr->lvl[0] = pyr->own0;
-        pyr->pitch[0] = pyr->w[0];
-        pyr->img_stride[0] = (int64_t)pyr->w[0] * pyr->h[0];
     } else {
         pyr->lvl[0] = const_cast<uint8_t *>(img);
         pyr->pitch[0] = row_stride;
         pyr->img_stride[0] = img_stride;
     }
+    int rc = pyr_launch_levels(ctx, pyr);
+    if (rc) return rc;
+    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// Level 0 in a tight library-owned buffer (+ slack for 4-byte row reads): where host images are uploaded to.
+static int pyr_own_level0(vo_ctx *ctx, vo_pyr *pyr)
+{
+    const size_t need = (size_t)pyr->w[0] * pyr->h[0] * pyr->batch + 256;
+    if (pyr->own0_bytes < need) {
+        if (pyr->own0) { VO_HIP_CHECK(hipStreamSynchronize(ctx->stream)); VO_HIP_CHECK(hipFree(pyr->own0)); pyr->own0 = nullptr; }
+        hipError_t e = hipMalloc((void **)&pyr->own0, need);
+        if (e != hipSuccess) { vo_set_error("vo_pyr_build: device allocation of %zu bytes failed", need); return VO_ENOMEM; }
+        pyr->own0_bytes = need;
+    }
+    pyr->lvl[0] = pyr->own0;
+    pyr->pitch[0] = pyr->w[0];
+    pyr->img_stride[0] = (int64_t)pyr->w[0] * pyr->h[0];
+    return VO_OK;
+}
+
+// One host image into a one-image pyramid through caller-provided page-locked memory (w * h bytes at `pin`, which
+// must stay untouched until the stream has run the copy): nothing here waits for the device.
+int vo_pyr_build_pinned(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, uint8_t *pin)
+{
+    VO_REQUIRE(pyr->ctx == ctx && pyr->batch == 1, "vo_pyr_build: a one-image pyramid of this context is needed");
+    VO_REQUIRE(row_stride >= pyr->w[0], "vo_pyr_build: row_stride %lld < width %d", (long long)row_stride, pyr->w[0]);
+    int rc = pyr_own_level0(ctx, pyr);
+    if (rc) return rc;
+    const size_t w = (size_t)pyr->w[0], h = (size_t)pyr->h[0];
+    if ((size_t)row_stride == w) memcpy(pin, img, w * h);
+    else for (size_t y = 0; y < h; ++y) memcpy(pin + y * w, img + y * (size_t)row_stride, w);
+    VO_HIP_CHECK(hipMemcpyAsync(pyr->own0, pin, w * h, hipMemcpyHostToDevice, ctx->stream));
+    return pyr_launch_levels(ctx, pyr);
+}
+
+// Levels 1 .. max_level from level 0, asynchronous.
+static int pyr_launch_levels(vo_ctx *ctx, vo_pyr *pyr)
+{
     for (int l = 1; l <= pyr->max_level; ++l) {
         const int groups = (pyr->w[l] + 3) / 4;
         // eight output rows per lane unless that leaves fewer than ~2 wavefronts per SIMD
@@ -264,7 +298,6 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
     }
     VO_HIP_CHECK(hipGetLastError());
     pyr->built = true;
-    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
 

@@ -222,7 +222,7 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)win * 12, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
     const bool refit = good >= 4 && refine_iters > 0;
     // OpenCV refits with EPnP there; here Gauss-Newton on the same error, started from the winner where it lies
-    if (refit && (rc = vo_refine_pose_from_Rt_async(ctx, dX, dx, n, nullptr, dmask, K, dRt, win, nullptr, refine_iters, refined)))
+    if (refit && (rc = vo_refine_pose_from_Rt_async(ctx, dX, dx, n, nullptr, dmask, nullptr, K, dRt, win, nullptr, refine_iters, refined, nullptr)))
         return rc;
     if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipMemcpyAsync(pin_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -44,17 +44,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
     for (int i = i0 + lane; i < i1; i += 64) {
         bool in;
         if (PNP) {
-            double Xw = pa[3 * i], Yw = pa[3 * i + 1], Zw = pa[3 * i + 2];
-            double xc = m[0] * Xw + m[1] * Yw + m[2] * Zw + m[3];
-            double yc = m[4] * Xw + m[5] * Yw + m[6] * Zw + m[7];
-            double zc = m[8] * Xw + m[9] * Yw + m[10] * Zw + m[11];
-            zc = zc ? 1. / zc : 1;
-            xc *= zc;
-            yc *= zc;
-            float u = (float)(xc * fx + cx), v = (float)(yc * fy + cy);
-            float du = pb[2 * i] - u, dv = pb[2 * i + 1] - v;
-            float err = du * du + dv * dv;
-            in = err <= t;
+            in = vo_pnp_inlier(m, pa, pb, i, fx, fy, cx, cy, t);
         } else {
             double x1 = pa[2 * i], y1 = pa[2 * i + 1], x2 = pb[2 * i], y2 = pb[2 * i + 1];
             double a, b, c, d1, d2, s1, s2;
@@ -143,15 +133,17 @@ extern "C" int vo_score_pnp(vo_ctx *ctx, const float *X, const float *x, int n, 
 }
 
 // vo_score_pnp on device pointers whose point count (and, optionally, first model) is only known on the device:
-// n_cap bounds the count for the launch geometry, *n_dev is the count, models + 12 * *first_dev the first model.
-// Asynchronous on the context's stream.
+// n_cap bounds the count for the launch geometry, *n_dev is the count, models + 12 * *first_dev the first model;
+// counts_cleared: an earlier kernel has zeroed dcounts (needed when the points span several workgroups, which
+// add up their shares).  Asynchronous on the context's stream.
 int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
-                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks)
+                     const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks,
+                     bool counts_cleared)
 {
     if (H == 0) return VO_OK;
     const int chunks = n_cap > 0 ? (n_cap + SC_CHUNK - 1) / SC_CHUNK : 1;
     VO_REQUIRE(chunks <= 65535, "vo_score_pnp: n=%d exceeds %d points", n_cap, 65535 * SC_CHUNK);
-    if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)H * 4, ctx->stream));
+    if (chunks > 1 && !counts_cleared) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)H * 4, ctx->stream));
     const float t = (float)(thr * thr);
     dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
     hipLaunchKernelGGL(score_kernel<true>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, dX, dx, n_cap, dRt, H, K[0], K[4], K[2],

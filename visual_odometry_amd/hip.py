@@ -850,11 +850,13 @@ def solve_pnp_ransac(ctx: Context, X, x, K, thr: float, conf: float, max_iters: 
 
 def track_pnp(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, landmarks, K, thr: float, conf: float, max_iters: int,
               refine_iters: int = 10, klt_max_iters: int = 10, klt_eps: float = 0.001, klt_min_eig: float = 1e-2,
-              rng_state: Optional[int] = None):
+              rng_state: Optional[int] = None, next_image=None):
     """One tracked frame in one call: klt_track from prev to nxt, the status == 1 filter and solve_pnp_ransac on the
     survivors, with one synchronisation.  pts (n,2), landmarks (n,3), row for row; pyramids of one image each ->
     (next_pts (n,2) f32, status (n,) u8, Rt (3,4) f64 or None, inlier mask (n,) u8 over the input rows,
-    number of tracked rows, number of inliers, rng state after the draws).  numpy or torch, as the points are."""
+    number of tracked rows, number of inliers, rng state after the draws).  numpy or torch, as the points are.
+    next_image (H,W) uint8 of the same kind: nxt is built from it inside the call (as nxt.build would) instead of
+    beforehand; a host image then shares the page-locked upload of the points and nothing waits for it alone."""
     Kh = _k_host(K)
     prm = KltParams(int(klt_max_iters), float(klt_eps), float(klt_min_eig))
     if prev.batch != 1 or nxt.batch != 1:
@@ -881,10 +883,29 @@ def track_pnp(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, landmarks, K, thr:
         mem = VO_MEM_HOST
     if int(X.shape[0]) != n:
         raise ValueError("track_pnp: pts and landmarks differ in length")
+    img_ptr, img_stride = None, 0
+    if next_image is not None:
+        if _is_torch(next_image) != _is_torch(pts):
+            raise ValueError("track_pnp: next_image must be of the same kind (numpy / torch) as pts")
+        if _is_torch(next_image):
+            import torch
+            img = next_image
+            if not (img.is_cuda and img.dtype == torch.uint8 and img.dim() == 2 and img.stride(1) == 1):
+                raise ValueError("track_pnp: next_image must be a (H,W) uint8 GPU tensor with unit column stride")
+            img_stride = int(img.stride(0))
+            nxt._keep = img
+        else:
+            img = np.ascontiguousarray(next_image, dtype=np.uint8)
+            if img.ndim != 2:
+                raise ValueError("track_pnp: next_image must be (H,W)")
+            img_stride = int(img.strides[0])
+        if tuple(img.shape) != (nxt.height, nxt.width):
+            raise ValueError(f"track_pnp: next_image {tuple(img.shape)} vs pyramid {(nxt.height, nxt.width)}")
+        img_ptr = _ptr(img)
     state = ctypes.c_uint64(0xFFFFFFFFFFFFFFFF if rng_state is None else rng_state)
     Rt = np.zeros((3, 4))
     tracked, good = ctypes.c_int32(), ctypes.c_int32()
-    check(ctx.lib.vo_track_pnp(ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(X), n, ctypes.byref(prm),
+    check(ctx.lib.vo_track_pnp(ctx.handle, prev.handle, nxt.handle, img_ptr, img_stride, _ptr(p), _ptr(X), n, ctypes.byref(prm),
                                Kh.ctypes.data_as(_lib.c_f64p), float(thr), float(conf), int(max_iters), int(refine_iters),
                                ctypes.byref(state), _ptr(out), _ptr(st), Rt.ctypes.data_as(_lib.c_f64p), _ptr(mask),
                                ctypes.byref(tracked), ctypes.byref(good), mem), "vo_track_pnp")

@@ -24,10 +24,18 @@ def pyramid_pair(h: int, w: int, max_level: int, win: int = 21, device: int = 0)
 _last_next: Dict[Tuple[int, int, int, int, int], Tuple["weakref.ref", int]] = {}
 
 
-def pyramids_for_pair(img0, img1, max_level: int, win: int = 21, device: int = 0, reuse: bool = False):
+def forget_pyramids() -> None:
+    """Drop the record of which frame's pyramid sits where (the next call rebuilds both)."""
+    _last_next.clear()
+
+
+def pyramids_for_pair(img0, img1, max_level: int, win: int = 21, device: int = 0, reuse: bool = False,
+                      defer_next: bool = False):
     """Built pyramids (prev, next) of two frames of one size.  With reuse, a frame that is the very
     array object given as `img1` in the previous call keeps the pyramid built for it then (the caller
-    vouches that it has not been written to since): only the new frame is uploaded and filtered."""
+    vouches that it has not been written to since): only the new frame is uploaded and filtered.
+    defer_next: the pyramid of img1 is left to the caller, who must build it into the returned object
+    (hip.track_pnp does, given the image) before anything else uses it."""
     h, w = img0.shape
     key = (device, h, w, max_level, win)
     pair = pyramid_pair(h, w, max_level, win, device)
@@ -39,7 +47,8 @@ def pyramids_for_pair(img0, img1, max_level: int, win: int = 21, device: int = 0
     if slot is None:
         slot = 0
         pair[0].build(img0)
-    pair[1 - slot].build(img1)
+    if not defer_next:
+        pair[1 - slot].build(img1)
     try:
         _last_next[key] = (weakref.ref(img1), 1 - slot)
     except TypeError:           # not weak-referenceable (not an ndarray): nothing to remember

@@ -81,11 +81,17 @@ class PoseEstimation:
         if n == 0:
             return np.zeros((0, 2), np.float32), np.zeros((0, 1), np.uint8), None, np.zeros((0, 1), np.int32)
         ctx = _runtime.context()
-        p0, p1 = _runtime.pyramids_for_pair(a0, a1, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS, reuse=reuse_pyramids)
-        out, st, Rt, mask, _, good, _ = hip.track_pnp(
-            ctx, p0, p1, pts, pointcloud, self.K, thr=params.PNP_RANSAC_REPROJ_THRESHOLD, conf=params.PNP_RANSAC_CONFIDENCE,
-            max_iters=params.PNP_RANSAC_MAX_ITERS, refine_iters=10, klt_max_iters=params.KLT_N_ITERS, klt_eps=0.001,
-            klt_min_eig=params.KLT_MIN_EIGEN_THRESHOLD)
+        # the new frame's pyramid is built inside the call, its upload riding with the points'
+        p0, p1 = _runtime.pyramids_for_pair(a0, a1, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS, reuse=reuse_pyramids,
+                                            defer_next=True)
+        try:
+            out, st, Rt, mask, _, good, _ = hip.track_pnp(
+                ctx, p0, p1, pts, pointcloud, self.K, thr=params.PNP_RANSAC_REPROJ_THRESHOLD, conf=params.PNP_RANSAC_CONFIDENCE,
+                max_iters=params.PNP_RANSAC_MAX_ITERS, refine_iters=10, klt_max_iters=params.KLT_N_ITERS, klt_eps=0.001,
+                klt_min_eig=params.KLT_MIN_EIGEN_THRESHOLD, next_image=a1)
+        except Exception:
+            _runtime.forget_pyramids()          # the deferred pyramid may not have been built
+            raise
         if Rt is None:
             return out, st.reshape(n, 1), None, np.zeros((0, 1), np.int32)
         M = np.eye(4)
