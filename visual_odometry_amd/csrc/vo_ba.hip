@@ -527,8 +527,9 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 // OpenCV refits with its own PnP solver, this minimises the same reprojection error).
 // One workgroup: every iteration sums the 6x6 normal equations over the selected
 // correspondences (DPP wave sums, then across waves in LDS), lane 0 solves the damped
-// system by Cholesky.  Stops when the cost rises (the previous pose is returned), stops
-// improving by more than 1e-10 relative, or after max_iters.
+// system by Cholesky.  Stops when the cost rises (the previous pose is returned), when it stops
+// improving by more than 1e-10 relative, when a step falls below 1e-9 of the pose (that step is
+// taken; the cost reported is the one before it), or after max_iters.
 // ---------------------------------------------------------------------------
 #define REFINE_THREADS 512
 struct Pose6 { double v[6]; };
@@ -691,9 +692,17 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                         g[k] = v / A[k][k];
                     }
                     prev_cost = cost;
+                    double gmax = 0, cmax = 1;
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) { prev_cam[k] = cam[k]; cam[k] += g[k]; }
+                    for (int k = 0; k < 6; ++k) {
+                        prev_cam[k] = cam[k];
+                        cam[k] += g[k];
+                        gmax = fmax(gmax, fabs(g[k]));
+                        cmax = fmax(cmax, fabs(cam[k]));
+                    }
                     iters_done = it + 1;
+                    // a step nine digits below the pose: converged, and the pass that would only confirm it is saved
+                    if (gmax <= 1e-9 * cmax) stop = 1;
                 }
             }
 #pragma unroll

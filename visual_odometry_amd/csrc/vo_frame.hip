@@ -21,16 +21,6 @@
 #define FS_SAMPLES 256                      // samples of the first chunk
 #define FS_DRAWS (4 * FS_SAMPLES + 512)     // raw generator outputs kept on the device: room for 512 rejected draws
 
-struct FrameMeta {
-    int m;            // correspondences with status 1
-    int win;          // winning sample of the first chunk, -1: none
-    int best;         // its inlier count
-    int niters;       // the loop's iteration bound after the first chunk
-    int overflow;     // the raw draws did not suffice for FS_SAMPLES subsets
-    int pad[3];
-    double Rt[12];    // the winner
-};
-
 // One subset of four distinct indices drawn from position p of the raw generator output, as
 // RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another draw.
 // Returns the position after the subset; FS_DRAWS when the draws ran out (a subset whose last draw is the
@@ -58,7 +48,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
                                                                 const float *__restrict__ pts, int n,
                                                                 const uint32_t *__restrict__ raw_g, int c0, float *__restrict__ Xc,
                                                                 float *__restrict__ xc, int *__restrict__ orig,
-                                                                FrameMeta *__restrict__ meta, int *__restrict__ counts,
+                                                                vo_frame_meta *__restrict__ meta, int *__restrict__ counts,
                                                                 uint8_t *__restrict__ full, int *__restrict__ subsets)
 {
     __shared__ int wcount[FS_THREADS / 64];
@@ -149,11 +139,14 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
                                                                    int c0, int max_iters, double conf, const double *__restrict__ Rt,
                                                                    const float *__restrict__ Xc, const float *__restrict__ xc,
                                                                    const int *__restrict__ orig, double fx, double fy, double cx,
-                                                                   double cy, float t, FrameMeta *__restrict__ meta,
-                                                                   uint8_t *__restrict__ full)
+                                                                   double cy, float t, vo_frame_meta *__restrict__ meta,
+                                                                   uint8_t *__restrict__ full, int m_host,
+                                                                   int *__restrict__ out_counts, uint8_t *__restrict__ out_valid)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m = meta->m;
+    const int m = m_host >= 0 ? m_host : meta->m;
+    if (out_counts && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < c0; c += 64 * FM_WAVES) { out_counts[c] = counts[c]; out_valid[c] = valid[c]; }
     int niters = max_iters, best = -1, best_c = -1;
     bool stop = m < 4;
     for (int r = 0; r * 64 < c0 && !stop; ++r) {
@@ -172,9 +165,11 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
     }
     if (blockIdx.x == 0 && wv == 0) {
         if (lane == 0) {
+            meta->m = m;
             meta->win = best_c;
             meta->best = best_c >= 0 ? best : 0;
             meta->niters = niters;
+            if (m_host >= 0) meta->overflow = 0;
         }
         if (best_c >= 0 && lane < 12) meta->Rt[lane] = Rt[12 * (int64_t)best_c + lane];
     }
@@ -184,7 +179,22 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
     for (int k = 0; k < 12; ++k) mdl[k] = Rt[12 * (int64_t)best_c + k];
     const int i0 = blockIdx.x * FM_POINTS + wv * (FM_POINTS / FM_WAVES);
     const int i1 = min(m, i0 + FM_POINTS / FM_WAVES);
-    for (int i = i0 + lane; i < i1; i += 64) full[orig[i]] = vo_pnp_inlier(mdl, Xc, xc, i, fx, fy, cx, cy, t) ? 1 : 0;
+    for (int i = i0 + lane; i < i1; i += 64) full[orig ? orig[i] : i] = vo_pnp_inlier(mdl, Xc, xc, i, fx, fy, cx, cy, t) ? 1 : 0;
+}
+
+int vo_pnp_first_chunk_tail(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, int m_host, const int *row,
+                            const int32_t *dcounts, const uint8_t *dvalid, int c0, int max_iters, double conf, const double *K,
+                            double thr, const double *dRt, vo_frame_meta *d_meta, int32_t *out_counts, uint8_t *out_valid,
+                            uint8_t *d_mask, int refine_iters, double *d_ref)
+{
+    hipLaunchKernelGGL(frame_mask_kernel, dim3((n_cap + FM_POINTS - 1) / FM_POINTS), dim3(64 * FM_WAVES), 0, ctx->stream, dcounts,
+                       dvalid, c0, max_iters, conf, dRt, dX, dx, row, K[0], K[4], K[2], K[5], (float)(thr * thr), d_meta, d_mask,
+                       m_host, out_counts, out_valid);
+    VO_HIP_CHECK(hipGetLastError());
+    if (refine_iters > 0)
+        return vo_refine_pose_from_Rt_async(ctx, dX, dx, n_cap, m_host >= 0 ? nullptr : &d_meta->m, d_mask, row, K, dRt, 0, &d_meta->win,
+                                            refine_iters, nullptr, d_ref);
+    return VO_OK;
 }
 
 // mask[orig[j]] = mask_c[j] for the m survivors (the long path's mask comes in survivor order)
@@ -257,7 +267,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
     const size_t o_Xc = take((size_t)n * 12), o_xc = take((size_t)n * 8), o_orig = take((size_t)n * 4), o_maskc = take((size_t)n),
                  o_sub = take((size_t)c0 * 16), o_Rt = take((size_t)c0 * 96);
     const size_t out0 = off;
-    const size_t o_meta = take(sizeof(FrameMeta)), o_ref = take(64), o_counts = take((size_t)c0 * 4 + 4), o_valid = take((size_t)c0);
+    const size_t o_meta = take(sizeof(vo_frame_meta)), o_ref = take(64), o_counts = take((size_t)c0 * 4 + 4), o_valid = take((size_t)c0);
     const size_t head_bytes = off - out0;
     const size_t o_next = take(host ? (size_t)n * 8 : 0), o_status = take(host ? (size_t)n : 0), o_full = take(host ? (size_t)n : 0);
     const size_t out_bytes = off - out0;
@@ -272,13 +282,13 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
     float *d_Xc = (float *)(base + o_Xc), *d_xc = (float *)(base + o_xc);
     int *d_orig = (int *)(base + o_orig), *d_sub = (int *)(base + o_sub), *d_counts = (int *)(base + o_counts);
     uint8_t *d_maskc = (uint8_t *)(base + o_maskc), *d_valid = (uint8_t *)(base + o_valid);
-    FrameMeta *d_meta = (FrameMeta *)(base + o_meta);
+    vo_frame_meta *d_meta = (vo_frame_meta *)(base + o_meta);
     double *d_Rt = (double *)(base + o_Rt), *d_ref = (double *)(base + o_ref);
     const size_t img_bytes = host && next_image ? (((size_t)next->w[0] * next->h[0] + 255) & ~(size_t)255) : 0;
     void *pin;
     if ((rc = vo_pinned_reserve(ctx, img_bytes + in_bytes + out_bytes, &pin))) return rc;
     char *hin = (char *)pin + img_bytes, *hout = hin + in_bytes;       // hout mirrors base + out0
-    const FrameMeta *h_meta = (const FrameMeta *)(hout + (o_meta - out0));
+    const vo_frame_meta *h_meta = (const vo_frame_meta *)(hout + (o_meta - out0));
     const double *h_ref = (const double *)(hout + (o_ref - out0));
 
     // the new frame's pyramid first: its upload and the points' share the page-locked buffer, nothing waits
@@ -299,17 +309,13 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
     if (n >= 4) {
         if ((rc = vo_p3p_solve(ctx, d_Xc, d_xc, n, K, d_sub, c0, d_Rt, d_valid, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c0, nullptr, thr, d_counts, nullptr, true))) return rc;
-        hipLaunchKernelGGL(frame_mask_kernel, dim3((n + FM_POINTS - 1) / FM_POINTS), dim3(64 * FM_WAVES), 0, ctx->stream, d_counts,
-                           d_valid, c0, max_iters, conf, d_Rt, d_Xc, d_xc, d_orig, K[0], K[4], K[2], K[5], (float)(thr * thr), d_meta,
-                           d_full);
-        VO_HIP_CHECK(hipGetLastError());
-        if (refine_iters > 0 && (rc = vo_refine_pose_from_Rt_async(ctx, d_Xc, d_xc, n, &d_meta->m, d_full, d_orig, K, d_Rt, 0,
-                                                                   &d_meta->win, refine_iters, nullptr, d_ref)))
+        if ((rc = vo_pnp_first_chunk_tail(ctx, d_Xc, d_xc, n, -1, d_orig, d_counts, d_valid, c0, max_iters, conf, K, thr, d_Rt, d_meta,
+                                          nullptr, nullptr, d_full, refine_iters, d_ref)))
             return rc;
     }
     VO_HIP_CHECK(hipMemcpyAsync(hout, base + out0, host ? out_bytes : head_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const FrameMeta meta = *h_meta;
+    const vo_frame_meta meta = *h_meta;
     const int m = meta.m;
     *n_tracked = m;
     if (host) {

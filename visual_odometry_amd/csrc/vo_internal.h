@@ -96,6 +96,27 @@ int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, 
                                  const int *mask_row, const double *K, const double *dRt, int sel, const int *sel_dev,
                                  int max_iters, double *host_out, double *d_out);
 
+// What the device-side RANSAC bookkeeping of a first chunk of PnP samples leaves behind (vo_frame.hip).
+struct vo_frame_meta {
+    int m;            // correspondences (vo_track_pnp: those with status 1)
+    int win;          // winning sample of the first chunk, -1: none
+    int best;         // its inlier count
+    int niters;       // the loop's iteration bound after the first chunk
+    int overflow;     // vo_track_pnp: the raw draws did not suffice for the chunk's subsets
+    int pad[3];
+    double Rt[12];    // the winner
+};
+// vo_frame.hip: after the c0 candidates dRt (validity dvalid) have been scored into dcounts -- replay of OpenCV's loop
+// over them, the winner's inlier mask into d_mask[row[i]] (row = NULL: d_mask[i]) and the refit started from the
+// winner, all on device-resident state: the winner goes to *d_meta, the refit's {pose (6), cost, iterations} to d_ref.
+// m_host >= 0: the number of correspondences; < 0: it is d_meta->m, left there by an earlier kernel.  out_counts /
+// out_valid (optional): copies of dcounts / dvalid next to d_meta, so that one copy takes everything to the host.
+// Asynchronous.
+int vo_pnp_first_chunk_tail(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, int m_host, const int *row,
+                            const int32_t *dcounts, const uint8_t *dvalid, int c0, int max_iters, double conf, const double *K,
+                            double thr, const double *dRt, vo_frame_meta *d_meta, int32_t *out_counts, uint8_t *out_valid,
+                            uint8_t *d_mask, int refine_iters, double *d_ref);
+
 // vo_pyramid.hip: one host image into a one-image pyramid through page-locked memory the caller provides (w * h
 // bytes, untouched until the stream has run the copy); does not wait for the device.
 int vo_pyr_build_pinned(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, uint8_t *pin);

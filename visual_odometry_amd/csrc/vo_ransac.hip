@@ -165,27 +165,34 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     void *p;
     const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
     uint64_t state = state0;
-    std::unique_ptr<int32_t[]> subsets_buf(new (std::nothrow) int32_t[(size_t)S * 4]);
-    if (!subsets_buf) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
-    // page-locked read-back area: a chunk's counts (4096 ints), validity flags (4096 bytes in 4096 ints), candidate
-    // poses (4096 x 12 doubles), then the inlier mask (n bytes) and the refit's 8 doubles
+    std::unique_ptr<int32_t[]> subsets_buf;          // all S subsets; only a loop that outlives its first chunk needs them
+    // page-locked area.  Read back: a chunk's counts (4096 ints), validity flags (4096 bytes in 4096 ints), candidate
+    // poses (4096 x 12 doubles), then the inlier mask (n bytes) and the refit's 8 doubles.  Sent: the first chunk's
+    // subsets and, for host arrays, the points (copies out of page-locked memory do not hold the caller up).
+    const size_t back_bytes = (((size_t)4096 * 8 + (size_t)4096 * 96 + 64 + (size_t)n + 64) + 255) & ~(size_t)255;
+    const int c_first = ransac_chunk(0, 0, max_iters) < S ? ransac_chunk(0, 0, max_iters) : S;
     void *pin;
-    if ((rc = vo_pinned_reserve(ctx, (size_t)4096 * 8 + (size_t)4096 * 96 + 64 + (size_t)n + 64, &pin))) return rc;
+    if ((rc = vo_pinned_reserve(ctx, back_bytes + (size_t)c_first * 16 + (size_t)n * 20 + 64, &pin))) return rc;
     int32_t *counts = (int32_t *)pin;
     double *poses = (double *)((char *)pin + (size_t)4096 * 8);
     double *refined = poses + (size_t)4096 * 12;
     uint8_t *pin_mask = (uint8_t *)(refined + 8);
+    int32_t *pin_sub = (int32_t *)((char *)pin + back_bytes);
+    float *pin_X = (float *)(pin_sub + (size_t)c_first * 4), *pin_x = pin_X + (size_t)n * 3;
     double Rt[12] = {0};
-    int32_t *subsets = subsets_buf.get();
+    int32_t *subsets = nullptr;
     const float *dX = X, *dx = x;
     uint8_t *dmask = inlier_mask;
-    // staging slots 0, 1 (points), 2 (subsets), 4 (candidates), 5 (counts + flags), 6 (mask); slot 3 belongs to vo_refine_pose
+    // staging slots 0, 1 (points), 2 (subsets), 4 (candidates), 5 (counts + flags), 6 (mask), 7 (first chunk's results);
+    // slot 3 belongs to vo_refine_pose
     if (mem == VO_MEM_HOST) {
         if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 12, &p))) return rc; dX = (const float *)p;
         if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc; dx = (const float *)p;
         if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc; dmask = (uint8_t *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(pin_X, X, (size_t)n * 12);
+        memcpy(pin_x, x, (size_t)n * 8);
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, pin_X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, pin_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 16, &p))) return rc;
     int32_t *dsub = (int32_t *)p;
@@ -195,7 +202,65 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     int32_t *dcounts = (int32_t *)p;
     uint8_t *dvalid = (uint8_t *)(dcounts + S);
     RansacReplay loop(max_iters);
-    for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
+    int first = 0, round = 0;
+    {
+        // First chunk with one read-back: the loop over its candidates is replayed on the device, which lets the
+        // winner's mask and the refit follow without the host in between; the host then replays the loop itself on
+        // the returned counts and keeps the device's result only when both agree and the loop has ended.
+        const int c = ransac_chunk(0, 0, max_iters) < S ? ransac_chunk(0, 0, max_iters) : S;
+        const size_t o_ref = sizeof(vo_frame_meta), o_counts = o_ref + 64, o_valid = o_counts + (((size_t)c * 4 + 63) & ~(size_t)63),
+                     o_mask = o_valid + (((size_t)c + 63) & ~(size_t)63), out_bytes = o_mask + (mem == VO_MEM_HOST ? (size_t)n : 0);
+        if ((rc = vo_stage_reserve(ctx, 7, out_bytes, &p))) return rc;
+        char *dout = (char *)p;
+        uint8_t *dmask0 = mem == VO_MEM_HOST ? (uint8_t *)(dout + o_mask) : inlier_mask;
+        if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, pin_sub))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(dsub, pin_sub, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub, c, dRt, dvalid, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt, c, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
+        if ((rc = vo_pnp_first_chunk_tail(ctx, dX, dx, n, n, nullptr, dcounts, dvalid, c, max_iters, conf, K, thr, dRt, (vo_frame_meta *)dout,
+                                          (int32_t *)(dout + o_counts), (uint8_t *)(dout + o_valid), dmask0, refine_iters,
+                                          (double *)(dout + o_ref))))
+            return rc;
+        char *hout = (char *)pin;           // the read-back area is larger than this block
+        VO_HIP_CHECK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const vo_frame_meta meta = *(const vo_frame_meta *)hout;
+        loop.feed((const int32_t *)(hout + o_counts), (const uint8_t *)(hout + o_valid), 1, 0, c, n, 4, conf);
+        const bool agree = loop.best_c == meta.win && loop.niters == meta.niters && (loop.best_c < 0 || loop.best == meta.best);
+        first = c;
+        round = 1;
+        if (agree && (loop.finished() || first >= S)) {
+            if (rng_state) {
+                uint64_t st = state0;
+                if ((rc = vo_ransac_advance_state(&st, n, 4, loop.niters < S ? loop.niters : S))) return rc;
+                *rng_state = st;
+            }
+            if (loop.best_c < 0) return VO_OK;
+            memcpy(Rt, meta.Rt, sizeof(Rt));
+            const double *ref = (const double *)(hout + o_ref);
+            bool finite = refine_iters > 0;
+            for (int k = 0; k < 6 && finite; ++k) finite = isfinite(ref[k]);
+            if (finite) {
+                double R[9];
+                matrix_from_rotvec(ref, R);
+                for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) Rt[4 * r + cc] = R[3 * r + cc]; Rt[4 * r + 3] = ref[3 + r]; }
+            }
+            if (mem == VO_MEM_HOST) memcpy(inlier_mask, hout + o_mask, (size_t)n);
+            memcpy(Rt_out, Rt, sizeof(Rt));
+            *n_inliers = loop.best;
+            return VO_OK;
+        }
+        if (loop.best_c >= 0) {
+            if (agree) memcpy(Rt, meta.Rt, sizeof(Rt));
+            else VO_HIP_CHECK(hipMemcpy(Rt, dRt + (size_t)loop.best_c * 12, sizeof(Rt), hipMemcpyDeviceToHost));
+        }
+    }
+    if (first < S && !loop.finished()) {
+        subsets_buf.reset(new (std::nothrow) int32_t[(size_t)S * 4]);
+        if (!subsets_buf) { vo_set_error("vo_solve_pnp_ransac: out of host memory"); return VO_ENOMEM; }
+        subsets = subsets_buf.get();
+    }
+    for (; first < S && !loop.finished(); ++round) {
         const int c = ransac_chunk(round, first, loop.niters) < S - first ? ransac_chunk(round, first, loop.niters) : S - first;
         if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, subsets + (size_t)first * 4))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 4, subsets + (size_t)first * 4, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
