@@ -559,6 +559,45 @@ __device__ static void rotvec_of_Rt(const double *Rt, double *rv)
     rv[0] = scale * q0; rv[1] = scale * q1; rv[2] = scale * q2;
 }
 
+// Rotation matrix of a rotation vector and its derivatives with respect to the vector's three components
+// (dR/dw_k = [w_k w + w x ((I - R) e_k)]x R / |w|^2; [e_k]x at w = 0), row-major.  Per pose, not per point: the
+// refit's point loop then needs one matrix-vector product per derivative.
+__device__ static void rotation_and_derivatives(const double *w, double *R, double (*dR)[9])
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    if (th == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { R[k] = (k % 4 == 0); dR[0][k] = 0; dR[1][k] = 0; dR[2][k] = 0; }
+        dR[0][5] = -1; dR[0][7] = 1;
+        dR[1][2] = 1; dR[1][6] = -1;
+        dR[2][1] = -1; dR[2][3] = 1;
+        return;
+    }
+    double s, c;
+    sincos(th, &s, &c);
+    const double v[3] = {w[0] / th, w[1] / th, w[2] / th};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = (1 - c) * v[i] * v[j] + (i == j ? c : 0);
+    R[1] -= s * v[2]; R[2] += s * v[1];
+    R[3] += s * v[2]; R[5] -= s * v[0];
+    R[6] -= s * v[1]; R[7] += s * v[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double u[3] = {(k == 0) - R[k], (k == 1) - R[3 + k], (k == 2) - R[6 + k]};      // (I - R) e_k
+        const double m[3] = {(w[k] * w[0] + (w[1] * u[2] - w[2] * u[1])) / th2, (w[k] * w[1] + (w[2] * u[0] - w[0] * u[2])) / th2,
+                             (w[k] * w[2] + (w[0] * u[1] - w[1] * u[0])) / th2};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {           // column j of [m]x R = m x (column j of R)
+            dR[k][j] = m[1] * R[6 + j] - m[2] * R[3 + j];
+            dR[k][3 + j] = m[2] * R[j] - m[0] * R[6 + j];
+            dR[k][6 + j] = m[0] * R[3 + j] - m[1] * R[j];
+        }
+    }
+}
+
 // Start pose: `start` (rotation vector, translation), or -- when Rt_src is given -- the [R|t] at
 // Rt_src + 12 * (sel_dev ? *sel_dev : sel), converted on the device (a negative index: nothing to refine, NaN out).
 // n_dev (optional): the number of correspondences lives on the device.  mask_row (optional): correspondence i is
@@ -602,12 +641,32 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
         double acc[28];
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = 0;
+        double R[9], dR[3][9];
+        rotation_and_derivatives(cam, R, dR);
         for (int i = tid; i < n; i += REFINE_THREADS) {
             if (mask && !mask[mask_row ? mask_row[i] : i]) continue;
-            const double Xd[3] = {(double)X[3 * (int64_t)i], (double)X[3 * (int64_t)i + 1], (double)X[3 * (int64_t)i + 2]};
-            const double ob[2] = {(double)x[2 * (int64_t)i], (double)x[2 * (int64_t)i + 1]};
-            double rr[2], Jc[12], Jp[6];
-            ba_obs<true>(cam, Xd, K, ob, rr, Jc, Jp);
+            const double X0 = (double)X[3 * (int64_t)i], X1 = (double)X[3 * (int64_t)i + 1], X2 = (double)X[3 * (int64_t)i + 2];
+            const double Y0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + cam[3], Y1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + cam[4],
+                         Y2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + cam[5];
+            const double p0 = K.k[0] * Y0 + K.k[1] * Y1 + K.k[2] * Y2, p1 = K.k[3] * Y0 + K.k[4] * Y1 + K.k[5] * Y2,
+                         p2 = K.k[6] * Y0 + K.k[7] * Y1 + K.k[8] * Y2;
+            const double ip2 = 1.0 / p2;
+            double rr[2], Jc[12];
+            rr[0] = p0 * ip2 - (double)x[2 * (int64_t)i];
+            rr[1] = p1 * ip2 - (double)x[2 * (int64_t)i + 1];
+            const double a2 = -p0 * ip2 * ip2, b2 = -p1 * ip2 * ip2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {        // d(residual) / d(camera-frame point): also the translation columns
+                Jc[3 + k] = ip2 * K.k[k] + a2 * K.k[6 + k];
+                Jc[9 + k] = ip2 * K.k[3 + k] + b2 * K.k[6 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {        // rotation columns: through dR/dw_k applied to the landmark
+                const double d0 = dR[k][0] * X0 + dR[k][1] * X1 + dR[k][2] * X2, d1 = dR[k][3] * X0 + dR[k][4] * X1 + dR[k][5] * X2,
+                             d2 = dR[k][6] * X0 + dR[k][7] * X1 + dR[k][8] * X2;
+                Jc[k] = Jc[3] * d0 + Jc[4] * d1 + Jc[5] * d2;
+                Jc[6 + k] = Jc[9] * d0 + Jc[10] * d1 + Jc[11] * d2;
+            }
             int e = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -658,38 +717,43 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                 for (int a = 0; a < 6; ++a) { tr += A[a][a]; g[a] = -tot[21 + a]; }
 #pragma unroll
                 for (int a = 0; a < 6; ++a) A[a][a] += 1e-9 * tr / 6;
+                // L D L^T (unit lower triangle L below the diagonal of A, d_k on it): six reciprocals are the only
+                // divisions -- this lane's dependent float64 chain is what every other wavefront waits for
                 bool ok = true;
+                double inv_d[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {       // Cholesky, lower triangle in place
+                for (int k = 0; k < 6; ++k) {
                     double d = A[k][k];
 #pragma unroll
-                    for (int m = 0; m < k; ++m) d -= A[k][m] * A[k][m];
+                    for (int m = 0; m < k; ++m) d -= A[k][m] * A[k][m] * A[m][m];
                     ok = ok && d > 0;
-                    const double piv = sqrt(ok ? d : 1.0);
-                    A[k][k] = piv;
+                    A[k][k] = ok ? d : 1.0;
+                    inv_d[k] = 1.0 / A[k][k];
 #pragma unroll
                     for (int i = k + 1; i < 6; ++i) {
                         double v = A[i][k];
 #pragma unroll
-                        for (int m = 0; m < k; ++m) v -= A[i][m] * A[k][m];
-                        A[i][k] = v / piv;
+                        for (int m = 0; m < k; ++m) v -= A[i][m] * A[k][m] * A[m][m];
+                        A[i][k] = v * inv_d[k];
                     }
                 }
                 if (!ok) stop = 1;
                 else {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < 6; ++k) {        // L z = g
                         double v = g[k];
 #pragma unroll
                         for (int m = 0; m < k; ++m) v -= A[k][m] * g[m];
-                        g[k] = v / A[k][k];
+                        g[k] = v;
                     }
 #pragma unroll
-                    for (int k = 5; k >= 0; --k) {
+                    for (int k = 0; k < 6; ++k) g[k] *= inv_d[k];    // D y = z
+#pragma unroll
+                    for (int k = 5; k >= 0; --k) {       // L^T x = y
                         double v = g[k];
 #pragma unroll
                         for (int m = k + 1; m < 6; ++m) v -= A[m][k] * g[m];
-                        g[k] = v / A[k][k];
+                        g[k] = v;
                     }
                     prev_cost = cost;
                     double gmax = 0, cmax = 1;
