@@ -150,3 +150,30 @@ int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out)
     *out = ctx->pinned;
     return VO_OK;
 }
+
+struct CopySegs { uint32_t *dst[3]; const uint32_t *src[3]; unsigned words[3]; };
+__global__ __launch_bounds__(256) void copy_pinned_kernel(CopySegs s)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < s.words[0]) s.dst[0][i] = s.src[0][i];
+    else if (i - s.words[0] < s.words[1]) s.dst[1][i - s.words[0]] = s.src[1][i - s.words[0]];
+    else if (i - s.words[0] - s.words[1] < s.words[2]) s.dst[2][i - s.words[0] - s.words[1]] = s.src[2][i - s.words[0] - s.words[1]];
+}
+
+int vo_copy_pinned_async(vo_ctx *ctx, const vo_copy_seg *segs, int count)
+{
+    VO_REQUIRE(count >= 1 && count <= 3, "vo_copy_pinned_async: %d segments", count);
+    CopySegs s = {};
+    size_t total = 0;
+    for (int k = 0; k < count; ++k) {
+        VO_REQUIRE(segs[k].bytes % 4 == 0 && segs[k].bytes < (1ull << 31), "vo_copy_pinned_async: segment of %zu bytes", segs[k].bytes);
+        s.dst[k] = (uint32_t *)segs[k].dst;
+        s.src[k] = (const uint32_t *)segs[k].src;
+        s.words[k] = (unsigned)(segs[k].bytes / 4);
+        total += s.words[k];
+    }
+    if (total == 0) return VO_OK;
+    hipLaunchKernelGGL(copy_pinned_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, s);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}

@@ -76,6 +76,12 @@ int vo_klt_noalloc_setup(int device);
 // Page-locked host scratch of at least `bytes` (contents survive until the next call that asks for more).
 int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out);
 
+// Up to three small host arrays, already in page-locked memory, into device buffers by one kernel that reads them over
+// the bus (byte counts multiples of 4).  A copy engine would do the same, but handing over from the engine to the
+// compute queue leaves the queue idle for ~10-20 us, more than these few KB take.  Asynchronous.
+struct vo_copy_seg { void *dst; const void *src; size_t bytes; };
+int vo_copy_pinned_async(vo_ctx *ctx, const vo_copy_seg *segs, int count);
+
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
 

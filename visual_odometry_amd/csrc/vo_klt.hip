@@ -776,6 +776,7 @@ static int fill_levels(KltArgs &a, const vo_pyr *prev, const vo_pyr *next)
 // all keypoints of a call fit on the device at once, i.e. for single-frame, latency-bound calls.
 // VO_KLT_VARIANT=1 or =3 in the environment forces one of them (comparison runs, parity tests).
 #define KLT_ONE_PER_WAVE_MAX 8192     // 1024 SIMDs x 8 wavefronts
+#define KLT_READ_IN_PLACE_MAX 16384   // host keypoints up to this many are read from page-locked memory in place
 static int klt_variant(int64_t keypoints)
 {
     const char *e = getenv("VO_KLT_VARIANT");
@@ -837,25 +838,30 @@ extern "C" int vo_klt_track(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
         a.prev_pts = prev_pts; a.init_pts = init_pts; a.next_pts = next_pts; a.status = status; a.err = err;
         return launch_klt(ctx, a);
     }
-    void *d_in, *d_init = nullptr, *d_out, *d_st, *d_err;
-    if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
-    if (init_pts && (rc = vo_stage_reserve(ctx, 1, cnt * 8, &d_init))) return rc;
-    if ((rc = vo_stage_reserve(ctx, 2, cnt * 8, &d_out))) return rc;
-    if ((rc = vo_stage_reserve(ctx, 3, cnt, &d_st))) return rc;
-    if ((rc = vo_stage_reserve(ctx, 4, cnt * 4, &d_err))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(d_in, prev_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (init_pts) VO_HIP_CHECK(hipMemcpyAsync(d_init, init_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-    a.prev_pts = (const float *)d_in; a.init_pts = (const float *)d_init; a.next_pts = (float *)d_out;
-    a.status = (uint8_t *)d_st; a.err = (float *)d_err;
-    if ((rc = launch_klt(ctx, a))) return rc;
-    // results come back through page-locked memory: three copies in flight, one wait (a copy into pageable memory
-    // blocks the caller until it has landed)
-    void *pin;
-    if ((rc = vo_pinned_reserve(ctx, cnt * 13 + 64, &pin))) return rc;
+    // Host arrays travel through the context's page-locked buffer: [results (13 B per keypoint) | keypoints | start
+    // positions].  The results come back with one copy and one wait (a copy into pageable memory would block the caller
+    // until it has landed); the inputs of a single-frame call are read by the tracker in place (each keypoint once, over
+    // the bus: cheaper than the ~20 us a copy engine's hand-over to the compute queue costs), larger ones are copied.
+    void *pin, *d_res, *d_in = nullptr, *d_init = nullptr;
+    const size_t in_off = (cnt * 13 + 255) & ~(size_t)255, in_bytes = (cnt * 8 + 255) & ~(size_t)255;
+    if ((rc = vo_pinned_reserve(ctx, in_off + 2 * in_bytes, &pin))) return rc;
     char *hp = (char *)pin;
-    VO_HIP_CHECK(hipMemcpyAsync(hp, d_out, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (err) VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 8, d_err, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 12, d_st, cnt, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = vo_stage_reserve(ctx, 2, cnt * 13, &d_res))) return rc;
+    memcpy(hp + in_off, prev_pts, cnt * 8);
+    if (init_pts) memcpy(hp + in_off + in_bytes, init_pts, cnt * 8);
+    if (cnt <= KLT_READ_IN_PLACE_MAX) {
+        d_in = hp + in_off;
+        if (init_pts) d_init = hp + in_off + in_bytes;
+    } else {
+        if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
+        if (init_pts && (rc = vo_stage_reserve(ctx, 1, cnt * 8, &d_init))) return rc;
+        VO_HIP_CHECK(hipMemcpyAsync(d_in, hp + in_off, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (init_pts) VO_HIP_CHECK(hipMemcpyAsync(d_init, hp + in_off + in_bytes, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    a.prev_pts = (const float *)d_in; a.init_pts = (const float *)d_init; a.next_pts = (float *)d_res;
+    a.err = (float *)((char *)d_res + cnt * 8); a.status = (uint8_t *)d_res + cnt * 12;
+    if ((rc = launch_klt(ctx, a))) return rc;
+    VO_HIP_CHECK(hipMemcpyAsync(hp, d_res, cnt * 13, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(next_pts, hp, cnt * 8);
     if (err) memcpy(err, hp + cnt * 8, cnt * 4);
@@ -888,17 +894,25 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t cnt = (size_t)n * prev->batch;
     int rc;
-    void *d_in, *d_fwd, *d_back, *d_sf, *d_sb, *d_mask;
+    void *d_in, *d_fwd, *d_back, *d_sf, *d_sb, *d_mask, *pin = nullptr;
     if ((rc = vo_stage_reserve(ctx, 5, cnt * 8, &d_back))) return rc;
     if ((rc = vo_stage_reserve(ctx, 6, cnt, &d_sf))) return rc;
     if ((rc = vo_stage_reserve(ctx, 7, cnt, &d_sb))) return rc;
+    const size_t in_off = (cnt * 9 + 255) & ~(size_t)255;
     if (mem == VO_MEM_DEVICE) {
         d_in = const_cast<float *>(prev_pts); d_fwd = next_pts; d_mask = mask;
     } else {
-        if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
-        if ((rc = vo_stage_reserve(ctx, 2, cnt * 8, &d_fwd))) return rc;
-        if ((rc = vo_stage_reserve(ctx, 3, cnt, &d_mask))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(d_in, prev_pts, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        // page-locked buffer: [results (points, mask) | keypoints]; see vo_klt_track
+        if ((rc = vo_pinned_reserve(ctx, in_off + cnt * 8, &pin))) return rc;
+        if ((rc = vo_stage_reserve(ctx, 2, cnt * 9, &d_fwd))) return rc;
+        d_mask = (char *)d_fwd + cnt * 8;
+        memcpy((char *)pin + in_off, prev_pts, cnt * 8);
+        if (cnt <= KLT_READ_IN_PLACE_MAX) {
+            d_in = (char *)pin + in_off;
+        } else {
+            if ((rc = vo_stage_reserve(ctx, 0, cnt * 8, &d_in))) return rc;
+            VO_HIP_CHECK(hipMemcpyAsync(d_in, (char *)pin + in_off, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     KltArgs f = {};
     if ((rc = fill_levels(f, prev, next))) return rc;
@@ -918,11 +932,8 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
                        (uint8_t *)d_mask, (int64_t)cnt);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        void *pin;
-        if ((rc = vo_pinned_reserve(ctx, cnt * 9 + 64, &pin))) return rc;
         char *hp = (char *)pin;
-        VO_HIP_CHECK(hipMemcpyAsync(hp, d_fwd, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(hp + cnt * 8, d_mask, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(hp, d_fwd, cnt * 9, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         memcpy(next_pts, hp, cnt * 8);
         memcpy(mask, hp + cnt * 8, cnt);

@@ -191,8 +191,6 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
         if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc; dmask = (uint8_t *)p;
         memcpy(pin_X, X, (size_t)n * 12);
         memcpy(pin_x, x, (size_t)n * 8);
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, pin_X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, pin_x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 16, &p))) return rc;
     int32_t *dsub = (int32_t *)p;
@@ -214,7 +212,9 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
         char *dout = (char *)p;
         uint8_t *dmask0 = mem == VO_MEM_HOST ? (uint8_t *)(dout + o_mask) : inlier_mask;
         if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, pin_sub))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(dsub, pin_sub, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
+        // subsets and (host arrays) points to the device in one launch
+        const vo_copy_seg segs[3] = {{dsub, pin_sub, (size_t)c * 16}, {(void *)dX, pin_X, (size_t)n * 12}, {(void *)dx, pin_x, (size_t)n * 8}};
+        if ((rc = vo_copy_pinned_async(ctx, segs, mem == VO_MEM_HOST ? 3 : 1))) return rc;
         if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub, c, dRt, dvalid, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt, c, thr, dcounts, nullptr, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_pnp_first_chunk_tail(ctx, dX, dx, n, n, nullptr, dcounts, dvalid, c, max_iters, conf, K, thr, dRt, (vo_frame_meta *)dout,
@@ -325,8 +325,13 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     if (!subsets_buf) { vo_set_error("vo_find_fundamental_ransac: out of host memory"); return VO_ENOMEM; }
     // page-locked read-back area: a chunk's 3c counts and c solution counts (contiguous on the device too), room for the
     // 3c validity flags formed here, then the winner: F (9 doubles), its count, the inlier mask (n bytes)
+    // behind it, sent: the first chunk's subsets and the points (one launch copies them out of page-locked memory)
+    const size_t back_bytes = (((size_t)4096 * 20 + 128 + (size_t)n + 64) + 255) & ~(size_t)255;
+    const int c_first = ransac_chunk(0, 0, max_iters) < S ? ransac_chunk(0, 0, max_iters) : S;
     void *pin;
-    if ((rc = vo_pinned_reserve(ctx, (size_t)4096 * 20 + 128 + (size_t)n + 64, &pin))) return rc;
+    if ((rc = vo_pinned_reserve(ctx, back_bytes + (size_t)c_first * 28 + (size_t)n * 16 + 64, &pin))) return rc;
+    int32_t *pin_sub = (int32_t *)((char *)pin + back_bytes);
+    float *pin_m1 = (float *)(pin_sub + (size_t)c_first * 7), *pin_m2 = pin_m1 + (size_t)n * 2;
     int32_t *subsets = subsets_buf.get(), *counts = (int32_t *)pin;
     double *pin_F = (double *)((char *)pin + (size_t)4096 * 20);
     int32_t *pin_good = (int32_t *)(pin_F + 9);
@@ -343,14 +348,20 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     int32_t *dcounts = (int32_t *)p, *dnsol = dcounts + 3 * (size_t)S;
     if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc;
     uint8_t *dmask = (uint8_t *)p;
-    VO_HIP_CHECK(hipMemcpyAsync(d1, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(d2, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(pin_m1, m1, (size_t)n * 8);
+    memcpy(pin_m2, m2, (size_t)n * 8);
     RansacReplay loop(max_iters);
     for (int first = 0, round = 0; first < S && !loop.finished(); ++round) {
         const int c = ransac_chunk(round, first, loop.niters) < S - first ? ransac_chunk(round, first, loop.niters) : S - first;
         // the collinearity test of the sampler reads the points on the host
         if ((rc = vo_ransac_draw_subsets(&state, n, 7, c, m1, m2, 10000, subsets + (size_t)first * 7))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28, hipMemcpyHostToDevice, ctx->stream));
+        if (round == 0) {
+            memcpy(pin_sub, subsets, (size_t)c * 28);
+            const vo_copy_seg segs[3] = {{dsub, pin_sub, (size_t)c * 28}, {d1, pin_m1, (size_t)n * 8}, {d2, pin_m2, (size_t)n * 8}};
+            if ((rc = vo_copy_pinned_async(ctx, segs, 3))) return rc;
+        } else {
+            VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28, hipMemcpyHostToDevice, ctx->stream));
+        }
         if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub + (size_t)first * 7, c, dF + (size_t)first * 27, dnsol + first, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)first * 27, 3 * c, thr, dcounts + 3 * (size_t)first, nullptr, VO_MEM_DEVICE))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts + 3 * (size_t)first, (size_t)c * 12, hipMemcpyDeviceToHost, ctx->stream));
