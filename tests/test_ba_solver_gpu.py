@@ -41,10 +41,15 @@ def _start(F, ci):
     return int(np.count_nonzero(ci < int(F / 4) + 1))
 
 
-# 6 cameras: reduced system in LDS; 16: LDS beyond the default 64 KB; 26: reduced system kept in global memory
-@pytest.mark.parametrize("F,P,vis", [(6, 150, 0.7), (16, 300, 0.5), (26, 200, 0.4)])
-def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis):
+# 6 cameras: reduced system in LDS; 16: LDS beyond the default 64 KB; 26 and more: reduced system kept in global memory
+# and factorised in panels (26: 13 full panels; 60: the size of the end-to-end run's windows; 101: a ragged last panel),
+# or column by column ("columns": the earlier kernel, kept for comparison)
+@pytest.mark.parametrize("F,P,vis,solve", [(6, 150, 0.7, ""), (16, 300, 0.5, ""), (26, 200, 0.4, ""), (26, 200, 0.4, "columns"),
+                                           (60, 400, 0.3, ""), (101, 600, 0.3, "")])
+def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis, solve, monkeypatch):
     from visual_odometry_amd import hip
+    if solve:
+        monkeypatch.setenv("VO_BA_SOLVE", solve)
     pb = synth.ba_problem(F=F, P=P, visibility=vis, seed=F, obs_noise=0.4)
     ci, pi, K = pb["ci"], pb["pi"], pb["K"]
     obs = pb["obs"].astype(np.float64)

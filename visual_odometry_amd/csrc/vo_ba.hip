@@ -889,6 +889,8 @@ struct vo_ba {
     int cur = 0;
     bool linearized = false, have_candidate = false;
     size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
+    int solve_w = 0;       // panel width of the blocked solve of a system that is not (0: the column-at-a-time kernel)
+    size_t solve_lds = 0;
 };
 
 #define SCHUR_THREADS 1024
@@ -1056,6 +1058,151 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, d
     __syncthreads();  // every read of dinv (possibly aliasing dc) is done
     m = 0;
     for (int i = tid; i < n; i += SOLVE_THREADS) dc[i] = out[m++];
+    if (tid == 0) flag[0] = 1;
+}
+
+
+// The same factorisation for reduced systems that do not fit in LDS (more than 23 cameras: the reference's window
+// reaches back to its 20th-last keyframe and takes every frame since), still one workgroup, but blocked: a step
+// of ba_solve_kernel<false> touches the whole trailing matrix in global memory once per column and waits for it, 6F
+// times.  Here W columns at a time are staged in LDS as a panel (column-major: pan[c * ld + r] = A[k0 + r][k0 + c],
+// the right-hand side as the last row), factorised there with one barrier per column, written back, and applied to
+// the trailing matrix in one pass: A[i][j] -= sum_c (pan[i][c] / d_c) pan[j][c], a thread owning 4 x 4 tiles whose
+// operands it reads as 32-byte runs of the panel.  The back-substitution is blocked the same way: W rows of L^T at a
+// time come in with coalesced reads, the W x W triangle is solved in LDS, the rest of the vector is updated in one
+// pass.  flag[0] = 1 on success, 0 when a pivot is not positive.
+#define SOLVEB_THREADS 1024
+#define SOLVEB_MAX_W 12
+__global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n, int F, int W, double *__restrict__ A,
+                                                                          double *__restrict__ b, const double *__restrict__ Hcc,
+                                                                          const double *__restrict__ g, double lambda,
+                                                                          double *__restrict__ dc, int *__restrict__ flag)
+{
+    extern __shared__ double sl[];
+    __shared__ unsigned char dead_cam[256];
+    __shared__ double xs[SOLVEB_MAX_W];
+    const int ld = n + 1;                       // panel column length (rows k0 .. n, the last one the right-hand side)
+    double *pan = sl, *dinv = sl + (size_t)W * ld, *bs = dinv + n;
+    const int tid = threadIdx.x;
+    bool fail = false;              // every thread sees the same pivots: uniform
+    for (int c = tid; c < F; c += SOLVEB_THREADS) {
+        double sabs = 0;
+        for (int k = 0; k < 36; ++k) sabs += fabs(Hcc[36 * (int64_t)c + k]);
+        dead_cam[c] = sabs == 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < F * 36; t += SOLVEB_THREADS) {
+        const int c = t / 36, e = t - c * 36, i = e / 6, j = e - i * 6;
+        const bool dead = dead_cam[c];
+        double v = Hcc[t];
+        if (i == j) v += lambda * v + 1e-12;
+        if (dead) v = (i == j) ? 1.0 : 0.0;
+        const size_t at = (size_t)(6 * c + i) * n + 6 * c + j;
+        A[at] = dead ? v : A[at] + v;
+    }
+    for (int i = tid; i < n; i += SOLVEB_THREADS) b[i] -= g[i];
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += W) {
+        const int w = min(W, n - k0), rows = n - k0 + 1;
+        // panel in: rows k0 .. n-1 of columns k0 .. k0+w-1 (lower triangle), then the right-hand side
+        for (int e = tid; e < rows * w; e += SOLVEB_THREADS) {
+            const int r = e / w, c = e - r * w, i = k0 + r;
+            pan[c * ld + r] = i < n ? (c <= r ? A[(size_t)i * n + k0 + c] : 0.0) : b[k0 + c];
+        }
+        __syncthreads();
+        for (int c = 0; c < w; ++c) {
+            const double d = pan[c * ld + c];           // final since the previous barrier; same in every thread
+            if (!(d > 0.0)) {
+                fail = true;
+                break;
+            }
+            const double id = 1.0 / d;
+            if (tid == 0) dinv[k0 + c] = id;
+            const int nr = rows - c - 1, nc = w - c - 1;
+            for (int e = tid; e < nr * nc; e += SOLVEB_THREADS) {
+                const int c2 = c + 1 + e / nr, r = c + 1 + (e - (e / nr) * nr);
+                if (c2 <= r) pan[c2 * ld + r] -= pan[c * ld + r] * id * pan[c * ld + c2];
+            }
+            __syncthreads();
+        }
+        if (fail) break;
+        // panel out (the factor's columns stay unscaled: c_ik = L_ik d_k)
+        for (int e = tid; e < rows * w; e += SOLVEB_THREADS) {
+            const int r = e / w, c = e - r * w, i = k0 + r;
+            if (i < n) { if (c <= r) A[(size_t)i * n + k0 + c] = pan[c * ld + r]; }
+            else b[k0 + c] = pan[c * ld + r];
+        }
+        // trailing update in 4 x 4 tiles: rows t0 + 4 ti .. (matrix rows and the right-hand side), columns t0 + 4 tj ..
+        const int t0 = k0 + w, m = n - t0;
+        if (m > 0) {
+            const int tr = (m + 1 + 3) / 4, tc = (m + 3) / 4;
+            for (int t = tid; t < tr * tc; t += SOLVEB_THREADS) {
+                const int ti = t / tc, tj = t - ti * tc;
+                if (4 * tj > 4 * ti + 3) continue;                  // wholly above the diagonal
+                double acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
+                const int ri = w + 4 * ti, rj = w + 4 * tj;           // panel rows of the tile's rows / columns
+                for (int c = 0; c < w; ++c) {
+                    const double id = dinv[k0 + c];
+                    double fa[4], fb[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        fa[a] = ri + a < rows ? pan[c * ld + ri + a] * id : 0.0;
+                        fb[a] = rj + a < rows - 1 ? pan[c * ld + rj + a] : 0.0;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[a][q] += fa[a] * fb[q];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int i = t0 + 4 * ti + a;
+                    if (i > n) continue;
+                    double *row = i < n ? A + (size_t)i * n : b;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = t0 + 4 * tj + q;
+                        if (j < n && j <= i) row[j] -= acc[a][q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (fail) {
+        if (tid == 0) flag[0] = 0;
+        for (int i = tid; i < n; i += SOLVEB_THREADS) dc[i] = 0.0;
+        return;
+    }
+    // b holds z = L^-1 rhs; y = D^-1 z; L^T x = y, W rows of L^T at a time from the bottom
+    for (int i = tid; i < n; i += SOLVEB_THREADS) bs[i] = b[i] * dinv[i];
+    __syncthreads();
+    const int last = ((n - 1) / W) * W;
+    for (int k0 = last; k0 >= 0; k0 -= W) {
+        const int w = min(W, n - k0);
+        // rows k0 .. k0+w-1 of the factor, scaled: pan[r * ld + i] = A[k0 + r][i] / d_i for i < k0 + r
+        for (int r = 0; r < w; ++r)
+            for (int i = tid; i < k0 + r; i += SOLVEB_THREADS) pan[r * ld + i] = A[(size_t)(k0 + r) * n + i] * dinv[i];
+        __syncthreads();
+        for (int r = w - 1; r >= 0; --r) {          // the block's own triangle
+            const double xk = bs[k0 + r];
+            if (tid == 0) xs[r] = xk;
+            if (tid < r) bs[k0 + tid] -= pan[r * ld + k0 + tid] * xk;
+            __syncthreads();
+        }
+        for (int i = tid; i < k0; i += SOLVEB_THREADS) {
+            double v = bs[i];
+            for (int r = 0; r < w; ++r) v -= pan[r * ld + i] * xs[r];
+            bs[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SOLVEB_THREADS) dc[i] = dead_cam[i / 6] ? 0.0 : bs[i];
     if (tid == 0) flag[0] = 1;
 }
 
@@ -1253,6 +1400,21 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
                      hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
                 ba->lds_bytes = need;
             (void)hipGetLastError();
+            if (!ba->lds_bytes) {
+                // panel (W columns of n + 1 rows), the pivots' reciprocals and the right-hand side in LDS
+                const long budget = 150 * 1024 - 16 * (long)n;
+                long w = budget / (8 * ((long)n + 1));
+                if (w > SOLVEB_MAX_W) w = SOLVEB_MAX_W;
+                const size_t lds = ((size_t)w * (n + 1) + 2 * (size_t)n) * 8;
+                if (w >= 4 && hipFuncSetAttribute((const void *)ba_solve_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)lds) == hipSuccess) {
+                    ba->solve_w = (int)w;
+                    ba->solve_lds = lds;
+                }
+                (void)hipGetLastError();
+                const char *env = getenv("VO_BA_SOLVE");          // "columns": the column-at-a-time kernel (comparison runs, tests)
+                if (env && env[0] == 'c') ba->solve_w = 0;
+            }
         }
     }
     free(hci); free(hpi); free(cam32); free(pptr); free(pobs);
@@ -1301,6 +1463,9 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
                            ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+    else if (ba->solve_w)
+        hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, ba->solve_w,
+                           ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
     else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
                            ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
