@@ -177,6 +177,22 @@ def main():
         for name in ("track_and_pose",):
             if hasattr(PE, name):
                 timed(PE, name, name)
+        from visual_odometry_amd.vo_pipeline import bootstrap as bs, ransac as rs, featureExtraction as fe, featureMatching as fm
+        timed(cvo.ContinuousVO, "_bootstrap", "_bootstrap (whole)")
+        timed(cvo.ContinuousVO, "_bundle_adjustment", "_bundle_adjustment (whole)")
+        timed(fe.FeatureExtractor, "sift_arrays", "sift_arrays")
+        timed(fm.FeatureMatcher, "match_arrays", "match_arrays")
+        timed(bs.BootstrapInitializer, "_estimate_fundamental", "_estimate_fundamental (sift x2 + match + RANSAC)")
+        timed(bs.BootstrapInitializer, "_transform_matrix", "_transform_matrix")
+        timed(fe.FeatureExtractor, "corners", "corners")
+        from visual_odometry_amd import hip as _hip
+        from visual_odometry_amd.vo_pipeline import bundleAdjustment as bam
+        timed(cvo.ContinuousVO, "_ba_window", "_ba_window")
+        timed(bam.BundleAdjustment, "bundle_adjustment", "bundle_adjustment")
+        timed(_hip.BaSolver, "__init__", "BaSolver.__init__")
+        timed(_hip.BaSolver, "try_step", "BaSolver.try_step")
+        timed(_hip.BaSolver, "linearize", "BaSolver.linearize")
+        timed(_hip.BaSolver, "params", "BaSolver.params")
     per_frame = []
     while True:
         t0 = time.perf_counter()
@@ -196,7 +212,8 @@ def main():
                       "bootstrap_ms": float(per_frame[vo.frames_to_skip] * 1e3),
                       "rel_position_rms": rel, "max_rotation_deg": rot, "scale": scale,
                       "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
-                      **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()}} if parts else {})}))
+                      **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()},
+                          "calls_of_parts": {k: len(v) for k, v in parts.items()}} if parts else {})}))
 
 
 if __name__ == "__main__":

@@ -921,7 +921,8 @@ __device__ __forceinline__ void damped_point_inverse(const double *__restrict__ 
 // landmark p's observations.  One wavefront per landmark (grid-stride).  A lane owns
 // one column of the reduced system, (observation b, row j of its block): it keeps
 // z = Dp^-1 Hcp_b[j,:]^T, and for every observation a of the landmark (wave-uniform,
-// so Hcp_a comes through scalar loads) adds the six entries Hcp_a[i,:] . z.  With LDS
+// so Hcp_a comes through scalar loads) adds the six entries Hcp_a[i,:] . z -- those on or
+// below the diagonal of the reduced system, the half the factorisation reads.  With LDS
 // the workgroup sums into a private copy of the reduced system first.
 template <bool LDS>
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, int F, const int *__restrict__ pptr,
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
             const int ob = pobs[o0 + b];
             const double *y = Hcp + 18 * (int64_t)ob + 3 * j;
             const double y0 = y[0], y1 = y[1], y2 = y[2];
-            const int col = 6 * cam[ob] + j;
+            const int cb = cam[ob], col = 6 * cb + j;
             if (on) unsafeAtomicAdd(ra + col, y0 * u0 + y1 * u1 + y2 * u2);
             const double z0 = inv[0] * y0 + inv[1] * y1 + inv[2] * y2;
             const double z1 = inv[3] * y0 + inv[4] * y1 + inv[5] * y2;
@@ -965,11 +966,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
             for (int a = 0; a < k; ++a) {
                 const int oa = __builtin_amdgcn_readfirstlane(pobs[o0 + a]);
                 const double *x = Hcp + 18 * (int64_t)oa;
-                double *dst = Sa + (size_t)(6 * __builtin_amdgcn_readfirstlane(cam[oa])) * n + col;
+                const int ca = __builtin_amdgcn_readfirstlane(cam[oa]);
+                double *dst = Sa + (size_t)(6 * ca) * n + col;
+                // the solver reads the lower triangle only (row >= column): the other half is not formed
+                if (ca < cb) continue;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const double v = x[3 * i] * z0 + x[3 * i + 1] * z1 + x[3 * i + 2] * z2;
-                    if (on && v != 0.0) unsafeAtomicAdd(dst + (size_t)i * n, -v);
+                    if (on && v != 0.0 && (ca > cb || i >= j)) unsafeAtomicAdd(dst + (size_t)i * n, -v);
                 }
             }
         }

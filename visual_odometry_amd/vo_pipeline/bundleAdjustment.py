@@ -79,18 +79,16 @@ class BundleAdjustment:
     def _obs_start(n_cameras, camera_indices) -> int:
         """Number of leading observations whose Jacobian rows stay empty: those counted for the
         first int(F/4)+1 cameras (observations are expected sorted by camera)."""
-        start = 0
-        for j in range(int(n_cameras / 4) + 1):
-            start += int(np.count_nonzero(np.asarray(camera_indices) == j))
-        return start
+        ci = np.asarray(camera_indices)
+        return int(np.count_nonzero((ci >= 0) & (ci < int(n_cameras / 4) + 1)))
 
     @staticmethod
     def _camera_params(M: np.ndarray) -> np.ndarray:
         num_frames = M.shape[0]
         camera_params = np.zeros((num_frames, 6))
         camera_params[:, 3:6] = M[:, :, 3]
-        for i in range(num_frames):
-            camera_params[i, :3] = Rotation.from_matrix(np.asarray(M[i, :, :3], np.float64)).as_rotvec()
+        if num_frames:
+            camera_params[:, :3] = Rotation.from_matrix(np.asarray(M[:, :, :3], np.float64)).as_rotvec()
         return camera_params
 
     def _preprocess_data(self, M, landmarks, camera_indices, point_indices, keypoints):
@@ -127,8 +125,8 @@ class BundleAdjustment:
         cams = x[:6 * F].reshape(F, 6)
         adjusted_M = np.zeros(M.shape)
         adjusted_M[:, :, 3] = cams[:, 3:]
-        for i in range(F):
-            adjusted_M[i, :, :3] = Rotation.from_rotvec(cams[i, :3]).as_matrix()
+        if F:
+            adjusted_M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
         return adjusted_M, x[6 * F:].reshape(landmarks.shape).copy()
 
     def _levenberg_marquardt(self, x, F, P, ci, pi, obs, start, max_iters, ftol):

@@ -83,11 +83,24 @@ def window_indices(traj_per_frame: Sequence[np.ndarray]) -> Tuple[np.ndarray, np
     if ci.size == 0:
         return ci, np.zeros(0, np.int64), np.zeros(0, np.int64)
     flat = np.concatenate([np.asarray(t, np.int64) for t in traj_per_frame])
-    uniq, first, inv = np.unique(flat, return_index=True, return_inverse=True)
-    order = np.argsort(first, kind="stable")
-    rank = np.empty_like(order)
-    rank[order] = np.arange(order.size)
-    return ci, rank[inv].astype(np.int64), uniq[order]
+    lo = int(flat.min())
+    span = int(flat.max()) - lo + 1
+    if lo < 0 or span > 8 * flat.size + 1024:           # sparse ids: sort-based
+        uniq, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+        order = np.argsort(first, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.size)
+        return ci, rank[inv].astype(np.int64), uniq[order]
+    # dense ids (trajectory ids are consecutive integers): a table instead of a sort over all observations.  Written
+    # back to front, an id's slot ends up holding the position of its first occurrence.
+    first = np.full(span, -1, np.int64)
+    rel = flat - lo
+    first[rel[::-1]] = np.arange(flat.size - 1, -1, -1, dtype=np.int64)
+    ids = np.nonzero(first >= 0)[0]
+    ids = ids[np.argsort(first[ids], kind="stable")]     # order of first appearance
+    rank = np.empty(span, np.int64)
+    rank[ids] = np.arange(ids.size, dtype=np.int64)
+    return ci, rank[rel], ids + lo
 
 
 class ContinuousVO:
@@ -248,7 +261,7 @@ class ContinuousVO:
             old_frame_idx = frame_idx - look_back + i
             pose = T if old_frame_idx == frame_idx else self.frame_queue.get(look_back - i - 1).pose
             poses.append(np.asarray(pose)[0:3, 0:4])
-            kp, traj, _ = store.at_frame(old_frame_idx)
+            kp, traj, _ = store.at_frame(old_frame_idx, with_landmarks=False)
             kps.append(kp)
             trajs.append(traj)
         ci, pi, traj_of_point = window_indices(trajs)

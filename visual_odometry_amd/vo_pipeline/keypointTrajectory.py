@@ -212,16 +212,23 @@ class KeypointTrajectories:
         self.latest_frame = max(self.latest_frame, frame_idx)
 
     # ---- queries -----------------------------------------------------------------
-    def at_frame(self, frame_idx: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    def at_frame(self, frame_idx: int, with_landmarks: bool = True) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
         """Keypoints with known landmarks on frame_idx ->
-        (keypoints (N,2) float32, trajectory ids (N,) int32, landmarks (N,3) float32)."""
+        (keypoints (N,2) float32, trajectory ids (N,) int32, landmarks (N,3) float32).
+        with_landmarks=False (not in the reference) skips the landmark gather and returns None in its place,
+        for callers that only want the observations (the bundle-adjustment window)."""
         assert frame_idx in self.on_frame, f"frame_idx {frame_idx} needs to have keypoints associated with it"
         obs = self.on_frame[frame_idx]
         ids = obs.ids
         lid = self.traj2landmark.lookup(ids)
         keep = lid >= 0
-        return (obs.pts[keep].astype(np.float32), ids[keep].astype(np.int32),
-                self.landmarks.array[lid[keep]].astype(np.float32).reshape(-1, 3))
+        if keep.all():
+            pts, kept = obs.pts.astype(np.float32), ids.astype(np.int32)
+        else:
+            pts, kept, lid = obs.pts[keep].astype(np.float32), ids[keep].astype(np.int32), lid[keep]
+        if not with_landmarks:
+            return pts, kept, None
+        return pts, kept, self.landmarks.array[lid].astype(np.float32).reshape(-1, 3)
 
     def trajectory(self, traj_idx: int) -> Trajectory:
         """Per-trajectory record; the point of a skipped frame repeats the next registered one."""
