@@ -112,6 +112,8 @@ def _declare_sift(L):
                                            ctypes.POINTER(ctypes.c_int)]
     L.vo_or_sift_num_octaves.restype = ctypes.c_int
     L.vo_or_sift_num_octaves.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.vo_or_sift_sincos.restype = None
+    L.vo_or_sift_sincos.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.vo_or_sift_gauss_kernel.restype = ctypes.c_int
     L.vo_or_sift_gauss_kernel.argtypes = [ctypes.c_double, _f32p]
 
@@ -343,6 +345,19 @@ def sift_pyramid_image(img, octave, index, dog=False, n_octave_layers=4, sigma=1
     lib().vo_or_sift_pyramid_image(_p(img, _u8p), h, w, w, int(n_octave_layers), float(sigma), int(dog), int(octave),
                                    int(index), _p(out, _f32p), ctypes.byref(ow), ctypes.byref(oh))
     return out
+
+
+def sift_sincos(t):
+    """(cos, sin) of float32 radians as the SIFT descriptor's rotation takes them (written-out float64 evaluation, see
+    vo_or_sift_sincos); scalar or array -> float32 arrays."""
+    t = np.atleast_1d(np.asarray(t, np.float32))
+    c, s = np.empty(t.shape, np.float32), np.empty(t.shape, np.float32)
+    cc, ss = ctypes.c_float(), ctypes.c_float()
+    f = lib().vo_or_sift_sincos
+    for i, v in enumerate(t.ravel()):
+        f(float(v), ctypes.byref(cc), ctypes.byref(ss))
+        c.ravel()[i], s.ravel()[i] = cc.value, ss.value
+    return c, s
 
 
 def sift_gauss_kernel(sigma):

@@ -41,6 +41,31 @@
 typedef struct { float x, y, size, angle, response; int32_t octave; } sift_kp;
 
 static int sift_round(double v) { return (int)lrint(v); }       /* cvRound: to nearest, ties to even */
+
+/* cos and sin of a float angle t (radians, 0 <= t <= 2 pi) as OpenCV's descriptor rotation takes them (cosf / sinf of
+ * the float product angle * (float)(pi / 180)): evaluated in float64 -- argument reduced by multiples of pi/2 given in
+ * two parts, fdlibm's kernel polynomials on [-pi/4, pi/4] -- in this fixed operation order and rounded to float.  The
+ * float64 result is within one unit in its last place, so the float is the correctly rounded one except when the exact
+ * value lies within ~1e-16 (relative) of a float rounding boundary; written out (instead of calling libm) so that a
+ * CPU and a GPU evaluate the very same expression. */
+void vo_or_sift_sincos(float t, float *c, float *s)
+{
+    const double x = (double)t;
+    const int k = (int)(x * 0.63661977236758138 + 0.5);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double r2 = r * r;
+    const double sn = r + r * r2 * (-1.66666666666666324348e-01 + r2 * (8.33333333332248946124e-03 + r2 * (-1.98412698298579493134e-04 +
+                      r2 * (2.75573137070700676789e-06 + r2 * (-2.50507602534068634195e-08 + r2 * 1.58969099521155010221e-10)))));
+    const double cs = 1.0 - 0.5 * r2 + r2 * r2 * (4.16666666666666019037e-02 + r2 * (-1.38888888888741095749e-03 + r2 * (2.48015872894767294178e-05 +
+                      r2 * (-2.75573143513906633035e-07 + r2 * (2.08757232129817482790e-09 + r2 * -1.13596475577881948265e-11)))));
+    switch (k & 3) {
+    case 0: *c = (float)cs; *s = (float)sn; break;
+    case 1: *c = (float)-sn; *s = (float)cs; break;
+    case 2: *c = (float)-cs; *s = (float)-sn; break;
+    default: *c = (float)sn; *s = (float)-cs; break;
+    }
+}
+
 static int sift_floor(float v) { int i = (int)v; return i - (i > v); }
 
 /* 2^t: integer part by exponent arithmetic, fraction by a degree-6 polynomial (relative error ~2e-7).  Plain
@@ -256,8 +281,8 @@ static void descriptor(const float *img, int w, int h, float ptx, float pty, flo
 {
     const int d = SIFT_DESCR_WIDTH, n = SIFT_DESCR_HIST_BINS;
     const int px = sift_round(ptx), py = sift_round(pty);
-    float cos_t = (float)cos((double)(ori * (float)(3.14159265358979323846 / 180.))),
-          sin_t = (float)sin((double)(ori * (float)(3.14159265358979323846 / 180.)));
+    float cos_t, sin_t;
+    vo_or_sift_sincos(ori * (float)(3.14159265358979323846 / 180.), &cos_t, &sin_t);
     const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = SIFT_DESCR_SCL_FCTR * scl;
     int radius = sift_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
     const int rmax = (int)sqrt((double)w * w + (double)h * h);

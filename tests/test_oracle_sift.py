@@ -110,3 +110,15 @@ def test_keypoint_fields_and_limits(oracle):
     assert len(few) == 10 and np.array_equal(few, kp[:10]) and np.array_equal(d2, des[:10])
     flat, dflat = oracle.sift(np.full((40, 50), 128, np.uint8))
     assert len(flat) == 0 and dflat.shape == (0, 128)
+
+
+def test_descriptor_rotation_matches_libm(oracle):
+    """The written-out cos / sin of the descriptor's rotation against numpy's (libm) float64 cos / sin rounded to
+    float32 -- what cosf / sinf return -- over the whole range of KeyPoint.angle and at the quadrant borders."""
+    rng = np.random.default_rng(11)
+    deg = np.concatenate([rng.uniform(0, 360, 40000).astype(np.float32),
+                          np.array([0, 45, 90, 135, 180, 225, 270, 315, 359.99997, 360, 1e-6, 89.99999, 90.00001], np.float32)])
+    t = deg * np.float32(np.pi / 180.0)
+    c, s = oracle.sift_sincos(t)
+    ref_c, ref_s = np.cos(t.astype(np.float64)).astype(np.float32), np.sin(t.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(c, ref_c) and np.array_equal(s, ref_s)

@@ -68,6 +68,30 @@ __device__ static inline float sift_exp2(float t)
 }
 __device__ static inline float sift_exp(float x) { return sift_exp2(x * 1.44269504088896341f); }
 
+// cos and sin of a float angle t (radians, 0 <= t <= 2 pi) as OpenCV's descriptor rotation takes them (cosf / sinf of
+// the float product angle * (float)(pi / 180)): evaluated in float64 -- argument reduced by multiples of pi/2 given in
+// two parts, fdlibm's kernel polynomials on [-pi/4, pi/4] -- in this fixed operation order and rounded to float.  The
+// float64 result is within one unit in its last place, so the float is the correctly rounded one except when the exact
+// value lies within ~1e-16 (relative) of a float rounding boundary; written out (instead of calling libm) so that a
+// CPU and a GPU evaluate the very same expression.
+__host__ __device__ static inline void sift_sincos(float t, float *c, float *s)
+{
+    const double x = (double)t;
+    const int k = (int)(x * 0.63661977236758138 + 0.5);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double r2 = r * r;
+    const double sn = r + r * r2 * (-1.66666666666666324348e-01 + r2 * (8.33333333332248946124e-03 + r2 * (-1.98412698298579493134e-04 +
+                      r2 * (2.75573137070700676789e-06 + r2 * (-2.50507602534068634195e-08 + r2 * 1.58969099521155010221e-10)))));
+    const double cs = 1.0 - 0.5 * r2 + r2 * r2 * (4.16666666666666019037e-02 + r2 * (-1.38888888888741095749e-03 + r2 * (2.48015872894767294178e-05 +
+                      r2 * (-2.75573143513906633035e-07 + r2 * (2.08757232129817482790e-09 + r2 * -1.13596475577881948265e-11)))));
+    switch (k & 3) {
+    case 0: *c = (float)cs; *s = (float)sn; break;
+    case 1: *c = (float)-sn; *s = (float)cs; break;
+    case 2: *c = (float)-cs; *s = (float)-sn; break;
+    default: *c = (float)sn; *s = (float)-cs; break;
+    }
+}
+
 // OpenCV's fastAtan2 polynomial: degrees in [0, 360)
 __device__ static inline float sift_atan2_deg(float y, float x)
 {
@@ -696,24 +720,23 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
             if (a.response != b.response) return a.response > b.response;
             return a.octave > b.octave;
         };
+        // x is the leading key and lies in [0, 2 * width): a counting sort on its integer part leaves buckets of a few
+        // keypoints each, which are then put in the full order (two linear passes and many tiny sorts instead of one
+        // comparison sort over tens of thousands of records)
+        const int nbuckets = 2 * width + 2;
         bool plain = true;
-        for (const auto &k : kps) plain = plain && k.x >= 0 && k.y >= 0;       // always true for SIFT; NaN or negative: full sort
-        if (plain) {
-            std::vector<std::pair<uint64_t, uint32_t>> order(kps.size());
-            for (size_t i = 0; i < kps.size(); ++i) {
-                uint32_t bx, by;
-                memcpy(&bx, &kps[i].x, 4); memcpy(&by, &kps[i].y, 4);
-                order[i] = {((uint64_t)bx << 32) | by, (uint32_t)i};
-            }
-            std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a.first < b.first; });
+        for (const auto &k : kps) plain = plain && k.x >= 0 && k.x < (float)(nbuckets - 1);   // always true for SIFT; else: full sort
+        if (plain && kps.size() > 64) {
+            std::vector<uint32_t> start((size_t)nbuckets + 1, 0);
+            for (const auto &k : kps) ++start[(size_t)(int)k.x + 1];
+            for (int b = 0; b < nbuckets; ++b) start[(size_t)b + 1] += start[b];
             std::vector<vo_sift_keypoint> sorted(kps.size());
-            for (size_t i = 0; i < kps.size(); ++i) sorted[i] = kps[order[i].second];
-            for (size_t i = 0; i < sorted.size();) {
-                size_t j = i + 1;
-                while (j < sorted.size() && order[j].first == order[i].first) ++j;
-                if (j - i > 1) std::sort(sorted.begin() + i, sorted.begin() + j, full_less);
-                i = j;
+            {
+                std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+                for (const auto &k : kps) sorted[fill[(size_t)(int)k.x]++] = k;
             }
+            for (int b = 0; b < nbuckets; ++b)
+                if (start[(size_t)b + 1] - start[b] > 1) std::sort(sorted.begin() + start[b], sorted.begin() + start[(size_t)b + 1], full_less);
             kps.swap(sorted);
         } else {
             std::sort(kps.begin(), kps.end(), full_less);
@@ -754,8 +777,8 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         jb.px = (int)lrint((double)ptx);
         jb.py = (int)lrint((double)pty);
         jb.ori = angle;
-        const float cos_t = (float)cos((double)(angle * (float)(3.14159265358979323846 / 180.))),
-                    sin_t = (float)sin((double)(angle * (float)(3.14159265358979323846 / 180.)));
+        float cos_t, sin_t;
+        sift_sincos(angle * (float)(3.14159265358979323846 / 180.), &cos_t, &sin_t);
         const float hist_width = SIFT_DESCR_SCL_FCTR * scl;
         int radius = (int)lrint((double)(hist_width * 1.4142135623730951f * (d + 1) * 0.5f));
         const int w = O.w[jb.octave], h = O.h[jb.octave];
@@ -765,7 +788,17 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         jb.sin_t = sin_t / hist_width;
     }
     // a wavefront serves four keypoints and lasts as long as the largest of their windows: neighbours of equal size
-    std::stable_sort(jobs.begin(), jobs.end(), [](const SiftJob &a, const SiftJob &b) { return a.radius > b.radius; });
+    // (stable counting sort on the radius, largest first)
+    {
+        int rtop = 0;
+        for (const auto &jb : jobs) rtop = jb.radius > rtop ? jb.radius : rtop;
+        std::vector<uint32_t> start((size_t)rtop + 2, 0);
+        for (const auto &jb : jobs) ++start[(size_t)(rtop - jb.radius) + 1];
+        for (int r = 0; r <= rtop; ++r) start[(size_t)r + 1] += start[r];
+        std::vector<SiftJob> by_radius(jobs.size());
+        for (const auto &jb : jobs) by_radius[start[(size_t)(rtop - jb.radius)]++] = jb;
+        jobs.swap(by_radius);
+    }
     if ((rc = vo_stage_reserve(ctx, 4, n_out * sizeof(SiftJob), &p))) return rc;
     SiftJob *d_jobs = (SiftJob *)p;
     float *d_desc = descriptors;
