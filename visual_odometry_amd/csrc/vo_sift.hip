@@ -385,8 +385,10 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict
 // Four keypoints per wavefront, sixteen lanes each.  Only the 4x4 inner cells of the 6x6x10 histogram reach the
 // descriptor, so a keypoint needs sixteen owners: lane l of a group owns inner cell (l / 4, l % 4) with its ten
 // orientation bins (LDS).  A group walks its keypoint's window sixteen positions at a time, keeps the samples that
-// fall inside the rotated 4x4 grid in a small buffer in raster order, and when the buffer fills every owner adds
-// the waiting samples that touch its cell, in that order -- the scalar algorithm's order of additions per bin.
+// fall inside the rotated 4x4 grid in a small buffer in raster order and marks them in a 64-bit word per owner whose
+// cell they touch; when the buffer fills every owner adds the samples marked in its word, lowest slot first -- the
+// scalar algorithm's order of additions per bin (a sample touches four of the sixteen cells, so an owner that walked
+// the whole buffer would skip three of four).
 #define SIFT_DESC_BUF 64
 __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftJob *__restrict__ jobs,
                                                             int n_jobs, float *__restrict__ desc)
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     __shared__ int s_cell[4][SIFT_DESC_BUF];
     __shared__ float s_dst[4][d * d * n];
     __shared__ float s_scale[4][2];
+    __shared__ unsigned long long s_touch[4][16];       // per owner: the waiting samples that touch its cell, one bit each
     const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
     const int job = blockIdx.x * 4 + g;
     const bool has = job < n_jobs;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     const int w = O.w[jb.octave], h = O.h[jb.octave];
     const float *img = pool + O.gauss_off[jb.octave] + (size_t)w * h * jb.layer;
     for (int t = gl; t < d * d * (n + 2); t += 16) hist[g][t] = 0.f;
+    s_touch[g][gl] = 0ull;
     const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
     const int radius = jb.radius, side = 2 * radius + 1, len = has ? side * side : 0;
     const int max_len = max(max(__shfl(len, 0), __shfl(len, 16)), max(__shfl(len, 32), __shfl(len, 48)));
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
         const int idx = base + gl;
         bool ok = false;
         float v[8];
-        int cell = 0;
+        int cell = 0, row6 = 0, col6 = 0;      // first of the (up to) four cells the sample touches, in the 6x6 grid
         if (idx < len) {
             const int i = idx / side - radius, j = idx % side - radius;
             const float c_rot = j * jb.cos_t - i * jb.sin_t, r_rot = j * jb.sin_t + i * jb.cos_t;
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
                 v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
                 v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
                 cell = (((r0 + 1) * (d + 2) + c0 + 1) << 8) | o0;          // first of the four cells it touches, orientation bin
+                row6 = r0 + 1;
+                col6 = c0 + 1;
             }
         }
         // compact in raster order behind the samples already waiting in the group's buffer
@@ -449,6 +455,14 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
             s_cell[g][at] = cell;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s_v[g][at][q] = v[q];
+            // tell the owners of the inner cells it touches (bit `at` of their word: order-free, so atomics may land in any order)
+#pragma unroll
+            for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+                for (int dc = 0; dc < 2; ++dc) {
+                    const int rr = row6 + dr, cc = col6 + dc;
+                    if (rr >= 1 && rr <= d && cc >= 1 && cc <= d) atomicOr(&s_touch[g][(rr - 1) * d + cc - 1], 1ull << at);
+                }
         }
         filled += __popc(gm);
         // when one group's buffer is full (or its window ends) all four groups empty theirs: the owners' loops then
@@ -457,20 +471,21 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int cnt = filled;
-            const int max_cnt = max(max(__shfl(cnt, 0), __shfl(cnt, 16)), max(__shfl(cnt, 32), __shfl(cnt, 48)));
-            for (int sidx = 0; sidx < max_cnt; ++sidx) {
-                if (sidx < cnt) {
+            // an owner visits the samples that touch its cell, lowest buffer slot first = raster order
+            unsigned long long todo = s_touch[g][gl];
+            while (__ballot(todo != 0ull) != 0) {
+                if (todo != 0ull) {
+                    const int sidx = __builtin_ctzll(todo);
+                    todo &= todo - 1;
                     const int cl = s_cell[g][sidx];
-                    // the sample touches cells b, b + 1, b + 6, b + 7 of the 6x6 grid (b + 1 stays in b's row: c0 + 1 <= 4)
+                    // the sample touches cells b, b + 1, b + 6, b + 7 of the 6x6 grid: this one is b + t, t = 6 dr + dc
                     const unsigned t = (unsigned)(my_cell - (cl >> 8));
-                    if (t < 8u && ((0xC3u >> t) & 1u)) {
-                        const int o0 = cl & 255, q = (int)((t >> 2) * 4 + (t & 1u) * 2);      // 4 * dr + 2 * dc
-                        mine[o0] += s_v[g][sidx][q];
-                        mine[o0 + 1] += s_v[g][sidx][q + 1];
-                    }
+                    const int o0 = cl & 255, q = (int)((t >> 2) * 4 + (t & 1u) * 2);          // 4 * dr + 2 * dc
+                    mine[o0] += s_v[g][sidx][q];
+                    mine[o0 + 1] += s_v[g][sidx][q + 1];
                 }
             }
+            s_touch[g][gl] = 0ull;
             filled = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

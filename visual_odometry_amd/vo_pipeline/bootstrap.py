@@ -70,6 +70,14 @@ class BootstrapInitializer:
         self.kps = kp1
         matcher = FeatureMatcher(MatcherType.FLANN, k=2, matching_threshold=params.MATCHING_THRESHOLD)
         idx, _, keep = matcher.match_arrays(des0, des1)
+        if not isinstance(des0, np.ndarray) and hasattr(des0, "is_cuda"):
+            # descriptors on the GPU: only the matched rows come back
+            import torch
+            qd = torch.nonzero(keep).ravel()
+            td = idx[qd, 0].long()
+            q, t = qd.cpu().numpy(), td.cpu().numpy()
+            logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
+            return kp0[q], kp1[t], des0[qd].cpu().numpy(), des1[td].cpu().numpy()
         q = np.nonzero(keep)[0]
         t = idx[q, 0]
         logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
@@ -77,8 +85,8 @@ class BootstrapInitializer:
 
     def _estimate_fundamental(self, normalize=False):
         if self.features is None and self.correspondences == "sift":
-            k0, d0 = FeatureExtractor.sift_arrays(self.img1)
-            k1, d1 = FeatureExtractor.sift_arrays(self.img2)
+            k0, d0 = FeatureExtractor.sift_arrays(self.img1, device_descriptors=True)
+            k1, d1 = FeatureExtractor.sift_arrays(self.img2, device_descriptors=True)
             self.features = (np.stack([k0["x"], k0["y"]], axis=1), d0, np.stack([k1["x"], k1["y"]], axis=1), d1)
         if self.features is not None:
             kp0, kp1, des0, des1 = self._matched_features()
