@@ -389,16 +389,22 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict
 // cell they touch; when the buffer fills every owner adds the samples marked in its word, lowest slot first -- the
 // scalar algorithm's order of additions per bin (a sample touches four of the sixteen cells, so an owner that walked
 // the whole buffer would skip three of four).
-#define SIFT_DESC_BUF 64
+#ifndef SIFT_DESC_BUF
+#define SIFT_DESC_BUF 64                 // waiting samples per keypoint (<= 64: one bit each in an owner's word)
+#endif
 __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftJob *__restrict__ jobs,
                                                             int n_jobs, float *__restrict__ desc)
 {
     constexpr int d = SIFT_DESCR_WIDTH, n = SIFT_DESCR_HIST_BINS;
+    // LDS per wavefront decides how many of them a CU holds, and with them how much of the gradient reads' latency is
+    // hidden: a waiting sample is kept as its four row/column shares and the orientation fraction (the owner splits a
+    // share over the two orientation bins with the same two operations the scalar algorithm uses), and the finished
+    // descriptor reuses the sample buffer
     __shared__ float hist[4][d * d * (n + 2)];
-    __shared__ float s_v[4][SIFT_DESC_BUF][8];
+    __shared__ float s_v[4][SIFT_DESC_BUF > 26 ? SIFT_DESC_BUF : 26][5];
     __shared__ int s_cell[4][SIFT_DESC_BUF];
-    __shared__ float s_dst[4][d * d * n];
     __shared__ float s_scale[4][2];
+    float (*s_dst)[d * d * n] = reinterpret_cast<float (*)[d * d * n]>(&s_v[0][0][0]);      // 4 x 128 floats <= 4 x 26 x 5
     __shared__ unsigned long long s_touch[4][16];       // per owner: the waiting samples that touch its cell, one bit each
     const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
     const int job = blockIdx.x * 4 + g;
@@ -414,14 +420,17 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     const int my_cell = ((gl >> 2) + 1) * (d + 2) + (gl & 3) + 1;      // index of this lane's cell in the 6x6 grid
     float *mine = hist[g] + gl * (n + 2);
     int filled = 0;                                                     // samples waiting in this group's buffer
+    int wi = gl / side, wj = gl - wi * side;                            // row and column of this lane's window position
     __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < max_len; base += 16) {
         const int idx = base + gl;
         bool ok = false;
-        float v[8];
+        float v[5];
         int cell = 0, row6 = 0, col6 = 0;      // first of the (up to) four cells the sample touches, in the 6x6 grid
+        const int i = wi - radius, j = wj - radius;
+        wj += 16;                               // the next position, sixteen further on in raster order
+        while (wj >= side) { wj -= side; ++wi; }
         if (idx < len) {
-            const int i = idx / side - radius, j = idx % side - radius;
             const float c_rot = j * jb.cos_t - i * jb.sin_t, r_rot = j * jb.sin_t + i * jb.cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = jb.py + i, c = jb.px + j;
@@ -439,10 +448,8 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
                 if (o0 >= n) o0 -= n;
                 const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
                 const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7];      // [r][c][o] -> index 4r + 2c + o
-                v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
-                v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3];
-                v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
+                v[0] = v_rc00; v[1] = v_rc01; v[2] = v_rc10; v[3] = v_rc11;      // [r][c] -> index 2r + c
+                v[4] = obin;
                 cell = (((r0 + 1) * (d + 2) + c0 + 1) << 8) | o0;          // first of the four cells it touches, orientation bin
                 row6 = r0 + 1;
                 col6 = c0 + 1;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
             const int at = filled + __popc(gm & ((1u << gl) - 1u));
             s_cell[g][at] = cell;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s_v[g][at][q] = v[q];
+            for (int q = 0; q < 5; ++q) s_v[g][at][q] = v[q];
             // tell the owners of the inner cells it touches (bit `at` of their word: order-free, so atomics may land in any order)
 #pragma unroll
             for (int dr = 0; dr < 2; ++dr)
@@ -480,9 +487,10 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
                     const int cl = s_cell[g][sidx];
                     // the sample touches cells b, b + 1, b + 6, b + 7 of the 6x6 grid: this one is b + t, t = 6 dr + dc
                     const unsigned t = (unsigned)(my_cell - (cl >> 8));
-                    const int o0 = cl & 255, q = (int)((t >> 2) * 4 + (t & 1u) * 2);          // 4 * dr + 2 * dc
-                    mine[o0] += s_v[g][sidx][q];
-                    mine[o0 + 1] += s_v[g][sidx][q + 1];
+                    const int o0 = cl & 255, q = (int)((t >> 2) * 2 + (t & 1u));              // 2 * dr + dc
+                    const float share = s_v[g][sidx][q], hi = share * s_v[g][sidx][4];
+                    mine[o0] += share - hi;
+                    mine[o0 + 1] += hi;
                 }
             }
             s_touch[g][gl] = 0ull;
