@@ -59,7 +59,10 @@ int vo_pyr_create(vo_ctx *ctx, int batch, int height, int width, int max_level, 
 int vo_pyr_destroy(vo_pyr *pyr);
 int vo_pyr_max_level(const vo_pyr *pyr);  /* effective last level (0-based) */
 int vo_pyr_level_shape(const vo_pyr *pyr, int level, int *height, int *width, int64_t *pitch);
-/* img: batch images, row stride `row_stride` bytes, image stride `img_stride` bytes. */
+/* img: batch images, row stride `row_stride` bytes, image stride `img_stride` bytes.  VO_MEM_HOST: the caller's
+ * buffer is free again when the call returns; the pyramid itself is built on the context's stream, ahead of
+ * whatever is queued on it next (images up to 1 MiB are staged in page-locked memory and nothing waits for the
+ * device; larger ones are uploaded and built before the call returns). */
 int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem);
 /* Copy one level of one image to a tight host buffer (tests / debugging). */
 int vo_pyr_download(vo_ctx *ctx, const vo_pyr *pyr, int image, int level, uint8_t *host_out);

@@ -434,11 +434,11 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
         d_r = (double *)(b + off[4]); d_cost = (double *)(b + off[5]);
         d_Hcc = (double *)(b + off[6]); d_Hpp = (double *)(b + off[7]); d_g = (double *)(b + off[8]);
         d_Hcp = (double *)(b + off[9]);
-        if (np_) VO_HIP_CHECK(hipMemcpyAsync((void *)d_params, params, np_ * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (np_) VO_UPLOAD(ctx, (void *)d_params, params, np_ * 8);
         if (O) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_obs, obs, (size_t)O * 16, hipMemcpyHostToDevice, ctx->stream));
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_ci, ci, (size_t)O * 8, hipMemcpyHostToDevice, ctx->stream));
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_pi, pi, (size_t)O * 8, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_obs, obs, (size_t)O * 16);
+            VO_UPLOAD(ctx, (void *)d_ci, ci, (size_t)O * 8);
+            VO_UPLOAD(ctx, (void *)d_pi, pi, (size_t)O * 8);
         }
     }
     VO_HIP_CHECK(hipMemsetAsync(d_cost, 0, 8, ctx->stream));
@@ -848,11 +848,11 @@ extern "C" int vo_refine_pose(vo_ctx *ctx, const float *X, const float *x, int n
     if (mem == VO_MEM_HOST && n) {
         if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 12, &p))) return rc; dX = (const float *)p;
         if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 8, &p))) return rc; dx = (const float *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dX, X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)dX, X, (size_t)n * 12);
+        VO_UPLOAD(ctx, (void *)dx, x, (size_t)n * 8);
         if (mask) {
             if ((rc = vo_stage_reserve(ctx, 2, (size_t)n, &p))) return rc; dm = (const uint8_t *)p;
-            VO_HIP_CHECK(hipMemcpyAsync((void *)dm, mask, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)dm, mask, (size_t)n);
         }
     }
     double h[8];

@@ -390,9 +390,9 @@ extern "C" int vo_connected_components(vo_ctx *ctx, const uint8_t *mask, int hei
         d_cent = centroids ? (double *)p : nullptr;
         d_areas = areas ? (int32_t *)((char *)p + (size_t)max_labels * 16) : nullptr;
         if (row_stride == width)
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_mask, mask, npix, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_mask, mask, npix);
         else
-            VO_HIP_CHECK(hipMemcpy2DAsync((void *)d_mask, width, mask, row_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD_2D(ctx, (void *)d_mask, mask, row_stride, width, height);
         pitch = width;
     }
     if ((rc = cc_run(ctx, wk, d_mask, pitch, d_labels, d_cent, d_areas, max_labels, nullptr, 0))) return rc;
@@ -437,9 +437,9 @@ extern "C" int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, in
     if (mem == VO_MEM_HOST) {
         if ((rc = vo_stage_reserve(ctx, 0, npix, &p))) return rc; d_img = (const uint8_t *)p;
         if (row_stride == width)
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_img, img, npix);
         else
-            VO_HIP_CHECK(hipMemcpy2DAsync((void *)d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD_2D(ctx, (void *)d_img, img, row_stride, width, height);
         pitch = width;
     }
     if ((rc = vo_stage_reserve(ctx, 2, npix, &p))) return rc;

@@ -76,6 +76,7 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
     for (auto &b : ctx->stage)
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -176,4 +177,113 @@ int vo_copy_pinned_async(vo_ctx *ctx, const vo_copy_seg *segs, int count)
     hipLaunchKernelGGL(copy_pinned_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, s);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_pinned_wide_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, unsigned n16)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+int vo_copy_pinned_wide_async(vo_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    VO_REQUIRE(((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 15) == 0 && bytes < (1ull << 34), "vo_copy_pinned_wide_async: bad block");
+    const unsigned n16 = (unsigned)((bytes + 15) / 16);
+    if (n16 == 0) return VO_OK;
+    hipLaunchKernelGGL(copy_pinned_wide_kernel, dim3((n16 + 255) / 256), dim3(256), 0, ctx->stream, (uint4 *)dst, (const uint4 *)src, n16);
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+// bulk in 16-byte pieces, the last bytes one by one (dst 16-byte aligned; src is, the ring hands out 256-byte aligned regions)
+__global__ __launch_bounds__(256) void upload_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src,
+                                                     unsigned n16, unsigned tail)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    else if (i - n16 < tail) dst[(size_t)n16 * 16 + (i - n16)] = src[(size_t)n16 * 16 + (i - n16)];
+}
+__global__ __launch_bounds__(256) void upload_bytes_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// The ring is kept small on purpose: its lines then stay in the CPU's cache from one upload to the next.  memcpy into
+// a region that has fallen out of the cache first reads every line from DRAM; with a 16 MiB ring two frame-sized
+// uploads cost 0.2 ms more than with 2 MiB (PoseEstimation.KLT: 0.33 against 0.13 ms).
+#define VO_UPLOAD_RING_BYTES ((size_t)2 << 20)
+#define VO_UPLOAD_MAX_BYTES ((size_t)1 << 20)
+
+// A 256-byte aligned region of the ring; waits for the stream before going round.
+static int upload_region(vo_ctx *ctx, size_t bytes, char **out)
+{
+    if (!ctx->up_ring) {
+        hipError_t e = hipHostMalloc((void **)&ctx->up_ring, VO_UPLOAD_RING_BYTES, hipHostMallocDefault);
+        if (e != hipSuccess) { vo_set_error("page-locked allocation of the upload ring failed: %s", hipGetErrorString(e)); return VO_ENOMEM; }
+        ctx->up_cap = VO_UPLOAD_RING_BYTES;
+        ctx->up_off = 0;
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (ctx->up_off + need > ctx->up_cap) {
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));        // every upload out of the ring has run
+        ctx->up_off = 0;
+    }
+    *out = ctx->up_ring + ctx->up_off;
+    ctx->up_off += need;
+    return VO_OK;
+}
+
+static int upload_launch(vo_ctx *ctx, void *dst, const char *ring, size_t bytes)
+{
+    if (((uintptr_t)dst & 15) == 0) {
+        const unsigned n16 = (unsigned)(bytes / 16), tail = (unsigned)(bytes % 16), threads = n16 + tail;
+        hipLaunchKernelGGL(upload_kernel, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, (unsigned char *)dst,
+                           (const unsigned char *)ring, n16, tail);
+    } else {
+        hipLaunchKernelGGL(upload_bytes_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned char *)dst,
+                           (const unsigned char *)ring, (unsigned)bytes);
+    }
+    VO_HIP_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_upload(vo_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return VO_OK;
+    if (bytes > VO_UPLOAD_MAX_BYTES) {
+        VO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
+    }
+    char *ring;
+    int rc = upload_region(ctx, bytes, &ring);
+    if (rc) return rc;
+    memcpy(ring, src, bytes);
+    return upload_launch(ctx, dst, ring, bytes);
+}
+
+int vo_upload_2d(vo_ctx *ctx, void *dst, const void *src, size_t src_stride, size_t width, size_t height)
+{
+    if (src_stride == width) return vo_upload(ctx, dst, src, width * height);
+    const size_t bytes = width * height;
+    if (bytes == 0) return VO_OK;
+    if (bytes > VO_UPLOAD_MAX_BYTES) {
+        VO_HIP_CHECK(hipMemcpy2DAsync(dst, width, src, src_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
+    }
+    char *ring;
+    int rc = upload_region(ctx, bytes, &ring);
+    if (rc) return rc;
+    for (size_t y = 0; y < height; ++y) memcpy(ring + y * width, (const char *)src + y * src_stride, width);
+    return upload_launch(ctx, dst, ring, bytes);
+}
+
+int vo_download_async(vo_ctx *ctx, void *pinned_dst, const void *dev_src, size_t bytes)
+{
+    if (bytes == 0) return VO_OK;
+    if ((((uintptr_t)pinned_dst | (uintptr_t)dev_src) & 15) != 0 || bytes > ((size_t)4 << 20)) {
+        VO_HIP_CHECK(hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return VO_OK;
+    }
+    return vo_copy_pinned_wide_async(ctx, pinned_dst, dev_src, bytes);
 }

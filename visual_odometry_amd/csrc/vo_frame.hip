@@ -317,7 +317,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
                                           nullptr, nullptr, d_full, refine_iters, d_ref)))
             return rc;
     }
-    VO_HIP_CHECK(hipMemcpyAsync(hout, base + out0, host ? out_bytes : head_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = vo_download_async(ctx, hout, base + out0, host ? out_bytes : head_bytes))) return rc;
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const vo_frame_meta meta = *h_meta;
     const int m = meta.m;

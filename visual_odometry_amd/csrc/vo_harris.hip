@@ -548,11 +548,10 @@ extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, in
         if ((rc = vo_stage_reserve(ctx, 0, npix * batch, &p))) return rc; d_img = (const uint8_t *)p;
         if ((rc = vo_stage_reserve(ctx, 1, npix * batch * 4, &p))) return rc; d_R = (float *)p;
         if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_img, img, npix * batch);
         } else {
             for (int b = 0; b < batch; ++b)
-                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
-                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+                VO_UPLOAD_2D(ctx, d_img + b * npix, img + (size_t)b * img_stride, row_stride, width, height);
         }
         pitch = width; istride = (int64_t)npix;
     }
@@ -642,7 +641,7 @@ extern "C" int vo_nms_topk(vo_ctx *ctx, const float *R, int batch, int height, i
         if ((rc = vo_stage_reserve(ctx, 2, (size_t)batch * K * 8, &p))) return rc; d_xy = (float *)p;
         if ((rc = vo_stage_reserve(ctx, 3, (size_t)batch * K * 4, &p))) return rc; d_sc = scores ? (float *)p : nullptr;
         if ((rc = vo_stage_reserve(ctx, 4, (size_t)batch * 4, &p))) return rc; d_cnt = (int *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_R, R, npix * batch * 4, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)d_R, R, npix * batch * 4);
     }
     if ((rc = vo_stage_reserve(ctx, 6, (size_t)batch * MAXKEY_STRIDE * 4, &p))) return rc;
     VO_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)batch * MAXKEY_STRIDE * 4, ctx->stream));
@@ -677,11 +676,10 @@ extern "C" int vo_detect_corners(vo_ctx *ctx, const uint8_t *img, int batch, int
         if ((rc = vo_stage_reserve(ctx, 3, (size_t)batch * K * 4, &p))) return rc; d_sc = scores ? (float *)p : nullptr;
         if ((rc = vo_stage_reserve(ctx, 4, (size_t)batch * 4, &p))) return rc; d_cnt = (int *)p;
         if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_img, img, npix * batch);
         } else {
             for (int b = 0; b < batch; ++b)
-                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
-                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+                VO_UPLOAD_2D(ctx, d_img + b * npix, img + (size_t)b * img_stride, row_stride, width, height);
         }
         pitch = width; istride = (int64_t)npix;
     }
@@ -788,11 +786,10 @@ extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int he
         if ((rc = vo_stage_reserve(ctx, 0, npix * batch, &p))) return rc; d_img = (const uint8_t *)p;
         if ((rc = vo_stage_reserve(ctx, 2, npix * batch, &p))) return rc; d_mask = (uint8_t *)p;
         if (row_stride == width && (batch == 1 || img_stride == (int64_t)npix)) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, npix * batch, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_img, img, npix * batch);
         } else {
             for (int b = 0; b < batch; ++b)
-                VO_HIP_CHECK(hipMemcpy2DAsync((void *)(d_img + b * npix), width, img + (size_t)b * img_stride, row_stride,
-                                              width, height, hipMemcpyHostToDevice, ctx->stream));
+                VO_UPLOAD_2D(ctx, d_img + b * npix, img + (size_t)b * img_stride, row_stride, width, height);
         }
         pitch = width; istride = (int64_t)npix;
     }

@@ -47,6 +47,9 @@ struct vo_ctx {
     const void *rng_raw_dev = nullptr;
     bool rng_raw_ok = false;
     int frame_path = 0;          // how the last vo_track_pnp ended (vo_track_pnp_path)
+    // page-locked ring that host arrays pass through on their way to the device (vo_upload)
+    char *up_ring = nullptr;
+    size_t up_cap = 0, up_off = 0;
 };
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
@@ -81,6 +84,32 @@ int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out);
 // compute queue leaves the queue idle for ~10-20 us, more than these few KB take.  Asynchronous.
 struct vo_copy_seg { void *dst; const void *src; size_t bytes; };
 int vo_copy_pinned_async(vo_ctx *ctx, const vo_copy_seg *segs, int count);
+// One larger block (a frame) the same way, 16 bytes per lane: both buffers 16-byte aligned with room for the byte count
+// rounded up to 16.
+int vo_copy_pinned_wide_async(vo_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+// Host array -> device buffer, asynchronous on the context's stream, the caller's memory free on return.  Arrays up to
+// 1 MiB are copied into a page-locked ring and brought over by a kernel that reads the ring across the bus (no copy
+// engine, so no hand-over to the compute queue in front of the kernel that consumes them -- worth ~100 us per frame-sized
+// upload on this platform); larger ones take hipMemcpyAsync.  A region of the ring is reused only after a wait for
+// the stream.  vo_upload_2d packs `height` rows of `width` bytes (source pitch `src_stride`) tightly.
+int vo_upload(vo_ctx *ctx, void *dst, const void *src, size_t bytes);
+int vo_upload_2d(vo_ctx *ctx, void *dst, const void *src, size_t src_stride, size_t width, size_t height);
+#define VO_UPLOAD(ctx, dst, src, bytes)                                                  \
+    do {                                                                                \
+        int _u = vo_upload((ctx), (void *)(dst), (src), (bytes));                       \
+        if (_u) return _u;                                                              \
+    } while (0)
+#define VO_UPLOAD_2D(ctx, dst, src, src_stride, width, height)                           \
+    do {                                                                                \
+        int _u = vo_upload_2d((ctx), (void *)(dst), (src), (src_stride), (width), (height)); \
+        if (_u) return _u;                                                              \
+    } while (0)
+
+// Device buffer -> page-locked host memory by a kernel that writes across the bus (both 16-byte aligned, room for the
+// byte count rounded up to 16 on both sides): the read-back then follows the producing kernel on the compute queue
+// instead of waiting for a copy engine to take over.  Asynchronous; the host reads after synchronising the stream.
+int vo_download_async(vo_ctx *ctx, void *pinned_dst, const void *dev_src, size_t bytes);
 
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);

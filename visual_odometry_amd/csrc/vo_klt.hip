@@ -861,7 +861,7 @@ extern "C" int vo_klt_track(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
     a.prev_pts = (const float *)d_in; a.init_pts = (const float *)d_init; a.next_pts = (float *)d_res;
     a.err = (float *)((char *)d_res + cnt * 8); a.status = (uint8_t *)d_res + cnt * 12;
     if ((rc = launch_klt(ctx, a))) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(hp, d_res, cnt * 13, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = vo_download_async(ctx, hp, d_res, cnt * 13))) return rc;
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(next_pts, hp, cnt * 8);
     if (err) memcpy(err, hp + cnt * 8, cnt * 4);
@@ -933,7 +933,7 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         char *hp = (char *)pin;
-        VO_HIP_CHECK(hipMemcpyAsync(hp, d_fwd, cnt * 9, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = vo_download_async(ctx, hp, d_fwd, cnt * 9))) return rc;
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         memcpy(next_pts, hp, cnt * 8);
         memcpy(mask, hp + cnt * 8, cnt);

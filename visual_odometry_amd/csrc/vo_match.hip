@@ -323,8 +323,8 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
         d_idx = (int32_t *)p;
         d_dist = (float *)((char *)p + (size_t)n1 * 8);
         d_keep = keep ? (uint8_t *)p + (size_t)n1 * 16 : nullptr;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d1, des1, b1, hipMemcpyHostToDevice, st));
-        if (n2) VO_HIP_CHECK(hipMemcpyAsync((void *)d2, des2, b2, hipMemcpyHostToDevice, st));
+        VO_UPLOAD(ctx, (void *)d1, des1, b1);
+        if (n2) VO_UPLOAD(ctx, (void *)d2, des2, b2);
     }
     const int n1p = div_up(n1, 256) * 256, n2p = div_up(n2 > 0 ? n2 : 1, 64) * 64;
     // split the train set so that each launch fills the device once: 256 CUs x 2 resident workgroups of either kernel

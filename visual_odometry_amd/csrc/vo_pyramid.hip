@@ -209,6 +209,7 @@ extern "C" int vo_pyr_level_shape(const vo_pyr *pyr, int level, int *height, int
 
 static int pyr_own_level0(vo_ctx *ctx, vo_pyr *pyr);
 static int pyr_launch_levels(vo_ctx *ctx, vo_pyr *pyr);
+#define PYR_STAGED_MAX_BYTES ((size_t)1 << 20)     // host images up to this size go through vo_upload's page-locked ring
 
 extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem)
 {
@@ -226,6 +227,14 @@ extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_
         int rc = pyr_own_level0(ctx, pyr);
         if (rc) return rc;
         const size_t img_bytes = (size_t)pyr->w[0] * pyr->h[0];
+        if (img_bytes <= PYR_STAGED_MAX_BYTES) {
+            // Frames of the drop-in calls pass through the context's page-locked ring (vo_upload): the caller's buffer is
+            // free when this returns and nothing waits for the device -- the upload and the level kernels queue on the
+            // stream ahead of whatever uses the pyramid.
+            for (int b = 0; b < pyr->batch; ++b)
+                VO_UPLOAD_2D(ctx, pyr->own0 + b * img_bytes, img + (size_t)b * img_stride, row_stride, pyr->w[0], pyr->h[0]);
+            return pyr_launch_levels(ctx, pyr);
+        }
         if (row_stride == pyr->w[0] && (pyr->batch == 1 || img_stride == (int64_t)img_bytes)) {
             // tight input: one linear copy (2-D copies from pageable memory go row by row)
             VO_HIP_CHECK(hipMemcpyAsync(pyr->own0, img, img_bytes * pyr->batch, hipMemcpyHostToDevice, ctx->stream));
@@ -272,7 +281,9 @@ int vo_pyr_build_pinned(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t ro
     const size_t w = (size_t)pyr->w[0], h = (size_t)pyr->h[0];
     if ((size_t)row_stride == w) memcpy(pin, img, w * h);
     else for (size_t y = 0; y < h; ++y) memcpy(pin + y * w, img + y * (size_t)row_stride, w);
-    VO_HIP_CHECK(hipMemcpyAsync(pyr->own0, pin, w * h, hipMemcpyHostToDevice, ctx->stream));
+    // by a kernel that reads the page-locked memory: a copy engine's hand-over to the compute queue would cost more than
+    // the frame takes over the bus (pin is 16-byte aligned with room for w * h rounded up to 16, as level 0 is)
+    if ((rc = vo_copy_pinned_wide_async(ctx, pyr->own0, pin, w * h))) return rc;
     return pyr_launch_levels(ctx, pyr);
 }
 

@@ -222,7 +222,7 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
                                           (double *)(dout + o_ref))))
             return rc;
         char *hout = (char *)pin;           // the read-back area is larger than this block
-        VO_HIP_CHECK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = vo_download_async(ctx, hout, dout, out_bytes))) return rc;
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const vo_frame_meta meta = *(const vo_frame_meta *)hout;
         loop.feed((const int32_t *)(hout + o_counts), (const uint8_t *)(hout + o_valid), 1, 0, c, n, 4, conf);
@@ -263,7 +263,7 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx *ctx, const float *X, const float *x, 
     for (; first < S && !loop.finished(); ++round) {
         const int c = ransac_chunk(round, first, loop.niters) < S - first ? ransac_chunk(round, first, loop.niters) : S - first;
         if ((rc = vo_ransac_draw_subsets(&state, n, 4, c, nullptr, nullptr, 1, subsets + (size_t)first * 4))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 4, subsets + (size_t)first * 4, (size_t)c * 16, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, dsub + (size_t)first * 4, subsets + (size_t)first * 4, (size_t)c * 16);
         if ((rc = vo_p3p_solve(ctx, dX, dx, n, K, dsub + (size_t)first * 4, c, dRt + (size_t)first * 12, dvalid + first, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_pnp(ctx, dX, dx, n, K, dRt + (size_t)first * 12, c, thr, dcounts + first, nullptr, VO_MEM_DEVICE))) return rc;
         VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts + first, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -360,7 +360,7 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
             const vo_copy_seg segs[3] = {{dsub, pin_sub, (size_t)c * 28}, {d1, pin_m1, (size_t)n * 8}, {d2, pin_m2, (size_t)n * 8}};
             if ((rc = vo_copy_pinned_async(ctx, segs, 3))) return rc;
         } else {
-            VO_HIP_CHECK(hipMemcpyAsync(dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, dsub + (size_t)first * 7, subsets + (size_t)first * 7, (size_t)c * 28);
         }
         if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub + (size_t)first * 7, c, dF + (size_t)first * 27, dnsol + first, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)first * 27, 3 * c, thr, dcounts + 3 * (size_t)first, nullptr, VO_MEM_DEVICE))) return rc;

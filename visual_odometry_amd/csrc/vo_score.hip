@@ -99,10 +99,10 @@ static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, co
         if ((rc = vo_stage_reserve(ctx, 3, (size_t)H * 4, &p))) return rc; d_c = (int *)p;
         if (masks) { if ((rc = vo_stage_reserve(ctx, 4, (size_t)H * n, &p))) return rc; d_k = (uint8_t *)p; }
         if (n) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_pa, pa, (size_t)n * PA * 4, hipMemcpyHostToDevice, ctx->stream));
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_pb, pb, (size_t)n * 2 * 4, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_pa, pa, (size_t)n * PA * 4);
+            VO_UPLOAD(ctx, (void *)d_pb, pb, (size_t)n * 2 * 4);
         }
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_m, models, (size_t)H * MS * 8, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)d_m, models, (size_t)H * MS * 8);
     }
     if (PNP) memcpy(Kh, K, sizeof(Kh));  // K is always a host pointer: it travels as kernel arguments
     const int chunks = n > 0 ? (n + SC_CHUNK - 1) / SC_CHUNK : 1;

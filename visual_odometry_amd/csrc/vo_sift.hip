@@ -646,9 +646,9 @@ static int sift_stage_image(vo_ctx *ctx, const uint8_t *img, int height, int wid
     int rc = vo_stage_reserve(ctx, 0, (size_t)width * height, &p);
     if (rc) return rc;
     if (row_stride == width)
-        VO_HIP_CHECK(hipMemcpyAsync(p, img, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, p, img, (size_t)width * height);
     else
-        VO_HIP_CHECK(hipMemcpy2DAsync(p, width, img, row_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD_2D(ctx, p, img, row_stride, width, height);
     *d_img = (const uint8_t *)p; *pitch = width;
     return VO_OK;
 }

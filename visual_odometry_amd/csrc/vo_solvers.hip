@@ -340,9 +340,9 @@ extern "C" int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, 
         if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 16, &p))) return rc; d_sub = (const int32_t *)p;
         if ((rc = vo_stage_reserve(ctx, 3, (size_t)S * 96, &p))) return rc; d_Rt = (double *)p;
         if ((rc = vo_stage_reserve(ctx, 4, (size_t)S, &p))) return rc; d_valid = (uint8_t *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_X, X, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_x, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_sub, subsets, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)d_X, X, (size_t)n * 12);
+        VO_UPLOAD(ctx, (void *)d_x, x, (size_t)n * 8);
+        VO_UPLOAD(ctx, (void *)d_sub, subsets, (size_t)S * 16);
     }
     hipLaunchKernelGGL(p3p_kernel, dim3((S + SOLVER_THREADS - 1) / SOLVER_THREADS), dim3(SOLVER_THREADS), 0, ctx->stream, d_X,
                        d_x, n, Kv, Ki, d_sub, S, d_Rt, d_valid);
@@ -376,9 +376,9 @@ extern "C" int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m
         if ((rc = vo_stage_reserve(ctx, 2, (size_t)S * 28, &p))) return rc; d_sub = (const int32_t *)p;
         if ((rc = vo_stage_reserve(ctx, 3, (size_t)S * 216, &p))) return rc; d_F = (double *)p;
         if ((rc = vo_stage_reserve(ctx, 4, (size_t)S * 4, &p))) return rc; d_n = (int32_t *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_m1, m1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_m2, m2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d_sub, subsets, (size_t)S * 28, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)d_m1, m1, (size_t)n * 8);
+        VO_UPLOAD(ctx, (void *)d_m2, m2, (size_t)n * 8);
+        VO_UPLOAD(ctx, (void *)d_sub, subsets, (size_t)S * 28);
     }
     hipLaunchKernelGGL(seven_point_kernel, dim3((S + SOLVER_THREADS - 1) / SOLVER_THREADS), dim3(SOLVER_THREADS), 0, ctx->stream,
                        d_m1, d_m2, n, d_sub, S, d_F, d_n);

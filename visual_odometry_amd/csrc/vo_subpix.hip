@@ -141,10 +141,10 @@ extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int
         if ((rc = vo_stage_reserve(ctx, 0, (size_t)width * height, &p))) return rc; d_img = (const uint8_t *)p;
         if ((rc = vo_stage_reserve(ctx, 2, (size_t)count * 8, &p))) return rc; d_c = (float *)p;
         if (row_stride == width)        // one linear copy: a 2D copy from pageable memory goes row by row
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d_img, img, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d_img, img, (size_t)width * height);
         else
-            VO_HIP_CHECK(hipMemcpy2DAsync((void *)d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(d_c, corners, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD_2D(ctx, (void *)d_img, img, row_stride, width, height);
+        VO_UPLOAD(ctx, d_c, corners, (size_t)count * 8);
         pitch = width;
     }
     hipLaunchKernelGGL(corner_subpix_kernel, dim3(count), dim3(64), 0, ctx->stream, d_img, height, width, pitch, d_c,

@@ -150,8 +150,8 @@ extern "C" int vo_triangulate(vo_ctx *ctx, const float *pts1, const float *pts2,
         if ((rc = vo_stage_reserve(ctx, 0, (size_t)n * 12, &p))) return rc; d1 = (const float *)p;
         if ((rc = vo_stage_reserve(ctx, 1, (size_t)n * 12, &p))) return rc; d2 = (const float *)p;
         if ((rc = vo_stage_reserve(ctx, 2, (size_t)n * 16, &p))) return rc; d_out = (float *)p;
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d1, pts1, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync((void *)d2, pts2, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        VO_UPLOAD(ctx, (void *)d1, pts1, (size_t)n * 12);
+        VO_UPLOAD(ctx, (void *)d2, pts2, (size_t)n * 12);
     }
     hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d1, d2, n, a, b, m1_is_f32 ? 1 : 0,
                        m2_is_f32 ? 1 : 0, d_out);
@@ -193,8 +193,8 @@ extern "C" int vo_cheirality_vote(vo_ctx *ctx, const float *pts1, const float *p
         d_cnt = (int32_t *)p;
         d_out = (float *)((char *)p + 64);
         if (n) {
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d1, pts1, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-            VO_HIP_CHECK(hipMemcpyAsync((void *)d2, pts2, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+            VO_UPLOAD(ctx, (void *)d1, pts1, (size_t)n * 12);
+            VO_UPLOAD(ctx, (void *)d2, pts2, (size_t)n * 12);
         }
     }
     VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * H, ctx->stream));
