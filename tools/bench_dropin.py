@@ -12,13 +12,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def t(fn, reps=20, warm=3):
+SPIKES = {}
+
+
+def t(fn, reps=40, warm=3):
+    """Median latency of fn in ms (a call in a few hundred takes milliseconds -- allocator or scheduler --, which a mean
+    over tens of calls would smear over all of them); the largest time seen is kept in SPIKES."""
     for _ in range(warm):
         fn()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         fn()
-    return (time.perf_counter() - t0) / reps * 1e3
+        ts.append(time.perf_counter() - t0)
+    SPIKES[len(SPIKES)] = max(ts) * 1e3
+    return float(np.median(ts)) * 1e3
 
 
 def _tm(p1, p2, sc, synth):
@@ -73,6 +81,7 @@ def main():
         f"BundleAdjustment.bundle_adjustment ms (10 keyframes x 2000 landmarks, {pb['ci'].size} observations, to ftol 1e-4)":
             t(lambda: ba.bundle_adjustment(M, landmarks, pb["ci"], pb["pi"], pb["obs"]), reps=5, warm=1),
     }
+    res["largest single call per entry, ms"] = [round(v, 3) for v in SPIKES.values()]
     print(json.dumps(res, indent=1))
 
 

@@ -1437,8 +1437,8 @@ extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem,
                                 ctx->stream));
     int rc = ba_linearize_into(ba, ba->cur);
     if (rc) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(cost, ba->cost[ba->cur], 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, cost, ba->cost[ba->cur], 8);
+    VO_RESULTS_FINISH(ctx);
     ba->linearized = true;
     ba->have_candidate = false;
     return VO_OK;
@@ -1480,9 +1480,9 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     VO_HIP_CHECK(hipGetLastError());
     int rc = ba_linearize_into(ba, o);
     if (rc) return rc;
-    VO_HIP_CHECK(hipMemcpyAsync(cost_new, ba->cost[o], 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(solved, ba->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, cost_new, ba->cost[o], 8);
+    VO_RESULT(ctx, solved, ba->flag, 4);
+    VO_RESULTS_FINISH(ctx);
     ba->have_candidate = true;
     return VO_OK;
 }

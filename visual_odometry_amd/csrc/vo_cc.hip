@@ -397,15 +397,15 @@ extern "C" int vo_connected_components(vo_ctx *ctx, const uint8_t *mask, int hei
     }
     if ((rc = cc_run(ctx, wk, d_mask, pitch, d_labels, d_cent, d_areas, max_labels, nullptr, 0))) return rc;
     int n_comp = 0;
-    VO_HIP_CHECK(hipMemcpyAsync(&n_comp, wk.meta, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, &n_comp, wk.meta, 4);
+    VO_RESULTS_FINISH(ctx);
     *n_labels = n_comp + 1;
     if (mem == VO_MEM_HOST) {
         const int rows = *n_labels < max_labels ? *n_labels : max_labels;
-        if (labels) VO_HIP_CHECK(hipMemcpyAsync(labels, d_labels, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (centroids && rows) VO_HIP_CHECK(hipMemcpyAsync(centroids, d_cent, (size_t)rows * 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (areas && rows) VO_HIP_CHECK(hipMemcpyAsync(areas, d_areas, (size_t)rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (labels) VO_RESULT(ctx, labels, d_labels, npix * 4);
+        if (centroids && rows) VO_RESULT(ctx, centroids, d_cent, (size_t)rows * 16);
+        if (areas && rows) VO_RESULT(ctx, areas, d_areas, (size_t)rows * 4);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }
@@ -455,10 +455,10 @@ extern "C" int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, in
     if ((rc = vo_corner_subpix_device(ctx, d_img, height, width, pitch, d_corners, max_corners, wk.meta, win_w, win_h, max_iters, eps)))
         return rc;
     int n_comp = 0;
-    VO_HIP_CHECK(hipMemcpyAsync(&n_comp, wk.meta, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_RESULT(ctx, &n_comp, wk.meta, 4);
     if (mem == VO_MEM_HOST)     // the count is not known yet: bring the whole buffer back in the same round trip
-        VO_HIP_CHECK(hipMemcpyAsync(corners, d_corners, (size_t)max_corners * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, corners, d_corners, (size_t)max_corners * 8);
+    VO_RESULTS_FINISH(ctx);
     *n_corners = n_comp + 1;
     return VO_OK;
 }

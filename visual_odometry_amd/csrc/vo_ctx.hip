@@ -77,6 +77,7 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
+    if (ctx->res_area) (void)hipHostFree(ctx->res_area);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -286,4 +287,43 @@ int vo_download_async(vo_ctx *ctx, void *pinned_dst, const void *dev_src, size_t
         return VO_OK;
     }
     return vo_copy_pinned_wide_async(ctx, pinned_dst, dev_src, bytes);
+}
+
+#define VO_RESULT_AREA_BYTES ((size_t)2 << 20)
+#define VO_RESULT_MAX_BYTES ((size_t)1 << 20)
+
+int vo_result(vo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (bytes == 0) return VO_OK;
+    if (!ctx->res_area) {
+        hipError_t e = hipHostMalloc((void **)&ctx->res_area, VO_RESULT_AREA_BYTES, hipHostMallocDefault);
+        if (e != hipSuccess) { vo_set_error("page-locked allocation of the result area failed: %s", hipGetErrorString(e)); return VO_ENOMEM; }
+        ctx->res_off = 0;
+        ctx->res_count = 0;
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (bytes > VO_RESULT_MAX_BYTES || ctx->res_count == 16 || ctx->res_off + need > VO_RESULT_AREA_BYTES) {
+        VO_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return VO_OK;
+    }
+    char *region = ctx->res_area + ctx->res_off;
+    int rc = vo_download_async(ctx, region, dev_src, bytes);
+    if (rc) return rc;
+    ctx->res_pending[ctx->res_count].dst = host_dst;
+    ctx->res_pending[ctx->res_count].src = region;
+    ctx->res_pending[ctx->res_count].bytes = bytes;
+    ++ctx->res_count;
+    ctx->res_off += need;
+    return VO_OK;
+}
+
+int vo_results_finish(vo_ctx *ctx)
+{
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    const int count = ctx->res_count;
+    ctx->res_count = 0;
+    ctx->res_off = 0;
+    if (e != hipSuccess) { vo_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); return VO_EHIP; }
+    for (int k = 0; k < count; ++k) memcpy(ctx->res_pending[k].dst, ctx->res_pending[k].src, ctx->res_pending[k].bytes);
+    return VO_OK;
 }

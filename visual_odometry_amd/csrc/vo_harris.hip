@@ -561,8 +561,8 @@ extern "C" int vo_harris_response(vo_ctx *ctx, const uint8_t *img, int batch, in
                        (uint32_t *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(R, d_R, npix * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, R, d_R, npix * batch * 4);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }
@@ -613,10 +613,10 @@ static int nms_select(vo_ctx *ctx, const float *d_R, int batch, int height, int 
 static int corners_copy_out(vo_ctx *ctx, int batch, int K, const float *d_xy, const float *d_sc, const int *d_cnt, float *xy,
                             float *scores, int32_t *count)
 {
-    VO_HIP_CHECK(hipMemcpyAsync(xy, d_xy, (size_t)batch * K * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (scores) VO_HIP_CHECK(hipMemcpyAsync(scores, d_sc, (size_t)batch * K * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(count, d_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, xy, d_xy, (size_t)batch * K * 8);
+    if (scores) VO_RESULT(ctx, scores, d_sc, (size_t)batch * K * 4);
+    VO_RESULT(ctx, count, d_cnt, (size_t)batch * 4);
+    VO_RESULTS_FINISH(ctx);
     return VO_OK;
 }
 
@@ -795,8 +795,8 @@ extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int he
     }
     if ((rc = harris_mask_launch(ctx, d_img, batch, height, width, pitch, istride, k, mode, rel_thresh, d_mask))) return rc;
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npix * batch, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, mask, d_mask, npix * batch);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }

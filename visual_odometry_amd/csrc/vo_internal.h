@@ -50,6 +50,11 @@ struct vo_ctx {
     // page-locked ring that host arrays pass through on their way to the device (vo_upload)
     char *up_ring = nullptr;
     size_t up_cap = 0, up_off = 0;
+    // page-locked area that results pass through on their way to the caller's arrays (vo_result / vo_results_finish)
+    char *res_area = nullptr;
+    size_t res_off = 0;
+    struct { void *dst; const char *src; size_t bytes; } res_pending[16];
+    int res_count = 0;
 };
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
@@ -110,6 +115,23 @@ int vo_upload_2d(vo_ctx *ctx, void *dst, const void *src, size_t src_stride, siz
 // byte count rounded up to 16 on both sides): the read-back then follows the producing kernel on the compute queue
 // instead of waiting for a copy engine to take over.  Asynchronous; the host reads after synchronising the stream.
 int vo_download_async(vo_ctx *ctx, void *pinned_dst, const void *dev_src, size_t bytes);
+
+// Device buffer -> the caller's (pageable) host array: vo_result queues a kernel that writes a page-locked region and
+// notes where the bytes belong; vo_results_finish waits for the stream once and copies every noted region home.  (A copy
+// straight into pageable memory blocks the caller per array, and a copy engine's hand-over costs more than these few KB.)
+// Arrays beyond 1 MiB, or more than 16 per call, take hipMemcpyAsync.
+int vo_result(vo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int vo_results_finish(vo_ctx *ctx);
+#define VO_RESULT(ctx, dst, src, bytes)                                                  \
+    do {                                                                                \
+        int _r = vo_result((ctx), (void *)(dst), (src), (bytes));                       \
+        if (_r) return _r;                                                              \
+    } while (0)
+#define VO_RESULTS_FINISH(ctx)                                                           \
+    do {                                                                                \
+        int _r = vo_results_finish(ctx);                                                \
+        if (_r) return _r;                                                              \
+    } while (0)
 
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);

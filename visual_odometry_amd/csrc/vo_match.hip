@@ -364,10 +364,10 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
                        d_dist, d_keep);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(idx, d_idx, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
-        VO_HIP_CHECK(hipMemcpyAsync(dist, d_dist, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
-        if (keep) VO_HIP_CHECK(hipMemcpyAsync(keep, d_keep, (size_t)n1, hipMemcpyDeviceToHost, st));
-        VO_HIP_CHECK(hipStreamSynchronize(st));
+        VO_RESULT(ctx, idx, d_idx, (size_t)n1 * 8);
+        VO_RESULT(ctx, dist, d_dist, (size_t)n1 * 8);
+        if (keep) VO_RESULT(ctx, keep, d_keep, (size_t)n1);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }

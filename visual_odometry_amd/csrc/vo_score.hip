@@ -113,9 +113,9 @@ static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, co
                        Kh[2], Kh[5], t, d_c, d_k, (const int *)nullptr, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(counts, d_c, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (masks && n) VO_HIP_CHECK(hipMemcpyAsync(masks, d_k, (size_t)H * n, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, counts, d_c, (size_t)H * 4);
+        if (masks && n) VO_RESULT(ctx, masks, d_k, (size_t)H * n);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }

@@ -348,9 +348,9 @@ extern "C" int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, 
                        d_x, n, Kv, Ki, d_sub, S, d_Rt, d_valid);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(Rt, d_Rt, (size_t)S * 96, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(valid, d_valid, (size_t)S, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, Rt, d_Rt, (size_t)S * 96);
+        VO_RESULT(ctx, valid, d_valid, (size_t)S);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }
@@ -384,9 +384,9 @@ extern "C" int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m
                        d_m1, d_m2, n, d_sub, S, d_F, d_n);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(F, d_F, (size_t)S * 216, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(nsol, d_n, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, F, d_F, (size_t)S * 216);
+        VO_RESULT(ctx, nsol, d_n, (size_t)S * 4);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }

@@ -151,8 +151,8 @@ extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int
                        count, win_w, win_h, max_iters, eps * eps, wt, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(corners, d_c, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, corners, d_c, (size_t)count * 8);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }

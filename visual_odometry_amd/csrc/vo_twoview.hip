@@ -157,8 +157,8 @@ extern "C" int vo_triangulate(vo_ctx *ctx, const float *pts1, const float *pts2,
                        m2_is_f32 ? 1 : 0, d_out);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULT(ctx, out, d_out, (size_t)n * 16);
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }
@@ -206,9 +206,9 @@ extern "C" int vo_cheirality_vote(vo_ctx *ctx, const float *pts1, const float *p
         VO_HIP_CHECK(hipGetLastError());
     }
     if (mem == VO_MEM_HOST) {
-        VO_HIP_CHECK(hipMemcpyAsync(in_front, d_cnt, sizeof(int32_t) * H, hipMemcpyDeviceToHost, ctx->stream));
-        if (n) VO_HIP_CHECK(hipMemcpyAsync(clouds, d_out, (size_t)H * n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the call's one synchronisation
+        VO_RESULT(ctx, in_front, d_cnt, sizeof(int32_t) * H);
+        if (n) VO_RESULT(ctx, clouds, d_out, (size_t)H * n * 16);
+        VO_RESULTS_FINISH(ctx);      // the call's one synchronisation
     }
     return VO_OK;
 }
