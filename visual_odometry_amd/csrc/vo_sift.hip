@@ -712,22 +712,22 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     }
     VO_HIP_CHECK(hipGetLastError());
     int h_cnt[2] = {0, 0};
-    VO_HIP_CHECK(hipMemcpyAsync(h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, h_cnt, d_cnt, 4);
+    VO_RESULTS_FINISH(ctx);
     if (h_cnt[0] > cand_cap) { vo_set_error("vo_sift_detect_compute: %d scale-space extrema exceed the candidate buffer (%d)", h_cnt[0], cand_cap); return VO_ESTATE; }
     if (h_cnt[0] > 0) {
         hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
                            (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp, d_cnt + 1, kp_cap);
         VO_HIP_CHECK(hipGetLastError());
     }
-    VO_HIP_CHECK(hipMemcpyAsync(h_cnt + 1, d_cnt + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    VO_RESULT(ctx, h_cnt + 1, d_cnt + 1, 4);
+    VO_RESULTS_FINISH(ctx);
     if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
     std::vector<vo_sift_keypoint> kps((size_t)h_cnt[1]);
     if (h_cnt[1]) {
         void *pin;      // through page-locked memory: a copy into pageable memory is staged in small pieces
         if ((rc = vo_pinned_reserve(ctx, kps.size() * sizeof(vo_sift_keypoint), &pin))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(pin, d_kp, kps.size() * sizeof(vo_sift_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = vo_download_async(ctx, pin, d_kp, kps.size() * sizeof(vo_sift_keypoint)))) return rc;
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         memcpy(kps.data(), pin, kps.size() * sizeof(vo_sift_keypoint));
     }
@@ -833,7 +833,7 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         void *pin;
         if ((rc = vo_pinned_reserve(ctx, n_out * sizeof(SiftJob), &pin))) return rc;
         memcpy(pin, jobs.data(), n_out * sizeof(SiftJob));
-        VO_HIP_CHECK(hipMemcpyAsync(d_jobs, pin, n_out * sizeof(SiftJob), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = vo_copy_pinned_wide_async(ctx, d_jobs, pin, n_out * sizeof(SiftJob)))) return rc;
     }
     hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
                        (const SiftJob *)d_jobs, (int)n_out, d_desc);
