@@ -327,3 +327,9 @@ int vo_results_finish(vo_ctx *ctx)
     for (int k = 0; k < count; ++k) memcpy(ctx->res_pending[k].dst, ctx->res_pending[k].src, ctx->res_pending[k].bytes);
     return VO_OK;
 }
+
+void vo_results_abandon(vo_ctx *ctx)
+{
+    ctx->res_count = 0;
+    ctx->res_off = 0;
+}

@@ -122,10 +122,11 @@ int vo_download_async(vo_ctx *ctx, void *pinned_dst, const void *dev_src, size_t
 // Arrays beyond 1 MiB, or more than 16 per call, take hipMemcpyAsync.
 int vo_result(vo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 int vo_results_finish(vo_ctx *ctx);
+void vo_results_abandon(vo_ctx *ctx);      // forget the noted regions (a call that fails between noting and finishing)
 #define VO_RESULT(ctx, dst, src, bytes)                                                  \
     do {                                                                                \
         int _r = vo_result((ctx), (void *)(dst), (src), (bytes));                       \
-        if (_r) return _r;                                                              \
+        if (_r) { vo_results_abandon(ctx); return _r; }                                 \
     } while (0)
 #define VO_RESULTS_FINISH(ctx)                                                           \
     do {                                                                                \
