@@ -193,6 +193,12 @@ def main():
         timed(_hip.BaSolver, "try_step", "BaSolver.try_step")
         timed(_hip.BaSolver, "linearize", "BaSolver.linearize")
         timed(_hip.BaSolver, "params", "BaSolver.params")
+        timed(_hip, "ba_residual", "hip.ba_residual")
+        timed(_hip, "_ba_prepare", "hip._ba_prepare")
+        timed(_hip.BaSolver, "accept", "BaSolver.accept")
+        timed(_hip.BaSolver, "close", "BaSolver.close")
+        timed(bam.BundleAdjustment, "_preprocess_data", "BA._preprocess_data")
+        timed(bam.BundleAdjustment, "_camera_params", "BA._camera_params", static=True)
     per_frame = []
     while True:
         t0 = time.perf_counter()
@@ -213,6 +219,7 @@ def main():
                       "rel_position_rms": rel, "max_rotation_deg": rot, "scale": scale,
                       "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
                       **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()},
+                          "total_ms_of_parts": {k: float(np.sum(v) * 1e3) for k, v in parts.items()},
                           "calls_of_parts": {k: len(v) for k, v in parts.items()}} if parts else {})}))
 
 

@@ -891,6 +891,9 @@ struct vo_ba {
     size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
     int solve_w = 0;       // panel width of the blocked solve of a system that is not (0: the column-at-a-time kernel)
     size_t solve_lds = 0;
+    int cam_first = 0;     // cameras below this one have no observation with Jacobian rows
+    int strip_cams = 0;    // cameras per strip of the strip-wise Schur complement of such a system (0: global atomics)
+    size_t strip_lds = 0;
 };
 
 #define SCHUR_THREADS 1024
@@ -963,17 +966,24 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
             const double z0 = inv[0] * y0 + inv[1] * y1 + inv[2] * y2;
             const double z1 = inv[3] * y0 + inv[4] * y1 + inv[5] * y2;
             const double z2 = inv[6] * y0 + inv[7] * y1 + inv[8] * y2;
-            for (int a = 0; a < k; ++a) {
-                const int oa = __builtin_amdgcn_readfirstlane(pobs[o0 + a]);
-                const double *x = Hcp + 18 * (int64_t)oa;
-                const int ca = __builtin_amdgcn_readfirstlane(cam[oa]);
-                double *dst = Sa + (size_t)(6 * ca) * n + col;
-                // the solver reads the lower triangle only (row >= column): the other half is not formed
-                if (ca < cb) continue;
+            // the landmark's observations and their cameras, 64 at a time in a register each: the loop below then takes
+            // them with a lane read instead of two dependent memory reads per step
+            for (int a0 = 0; a0 < k; a0 += 64) {
+                const int na = min(64, k - a0);
+                const int my_oa = lane < na ? pobs[o0 + a0 + lane] : 0;
+                const int my_ca = lane < na ? cam[my_oa] : 0;
+                for (int a = 0; a < na; ++a) {
+                    const int oa = __builtin_amdgcn_readlane(my_oa, a);
+                    const int ca = __builtin_amdgcn_readlane(my_ca, a);
+                    const double *x = Hcp + 18 * (int64_t)oa;
+                    double *dst = Sa + (size_t)(6 * ca) * n + col;
+                    // the solver reads the lower triangle only (row >= column): the other half is not formed
+                    if (ca < cb) continue;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const double v = x[3 * i] * z0 + x[3 * i + 1] * z1 + x[3 * i + 2] * z2;
-                    if (on && v != 0.0 && (ca > cb || i >= j)) unsafeAtomicAdd(dst + (size_t)i * n, -v);
+                    for (int i = 0; i < 6; ++i) {
+                        const double v = x[3 * i] * z0 + x[3 * i + 1] * z1 + x[3 * i + 2] * z2;
+                        if (on && v != 0.0 && (ca > cb || i >= j)) unsafeAtomicAdd(dst + (size_t)i * n, -v);
+                    }
                 }
             }
         }
@@ -984,6 +994,84 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
             if (sl[i] != 0.0) unsafeAtomicAdd(S + i, sl[i]);
         for (int i = threadIdx.x; i < n; i += SCHUR_THREADS)
             if (sl[(size_t)n * n + i] != 0.0) unsafeAtomicAdd(rhs + i, sl[(size_t)n * n + i]);
+    }
+}
+
+
+// The Schur complement of a reduced system too large for one LDS copy (more than 23 cameras): the system is cut into
+// strips of `sc` cameras' rows, and a workgroup sums one strip's share of its landmarks in LDS -- the same per-landmark
+// work as ba_schur_kernel, with the row blocks outside the strip skipped -- before adding it to global memory once.
+// blockIdx.y = strip, blockIdx.x = slice of the landmarks.  With the whole system in global memory every one of the
+// ~36 k^2 / 2 entries of a landmark seen k times is a float64 atomic on L2 (0.54 ms at 60 cameras and 20 000 landmarks);
+// here those land in LDS, and global memory sees one add per non-zero entry of a strip and workgroup.
+// Strip 0's workgroups also form Dp^-1 and the right-hand side.
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, int P, int F, int cam_first, int sc, const int *__restrict__ pptr,
+                                                                       const int *__restrict__ pobs, const int *__restrict__ cam,
+                                                                       const double *__restrict__ Hpp, const double *__restrict__ Hcp,
+                                                                       const double *__restrict__ g, double lambda,
+                                                                       double *__restrict__ Dpinv, double *__restrict__ S,
+                                                                       double *__restrict__ rhs)
+{
+    extern __shared__ double sl[];
+    const int c0 = cam_first + blockIdx.y * sc, c1 = min(F, c0 + sc);      // cameras of this strip
+    // only columns from the first camera with unknowns up to the strip's own diagonal blocks are needed
+    const int colbase = 6 * cam_first, rows = 6 * (c1 - c0), cols = 6 * c1 - colbase;
+    for (int i = threadIdx.x; i < rows * cols; i += SCHUR_THREADS) sl[i] = 0.0;
+    __syncthreads();
+    const bool first = blockIdx.y == 0;
+    const int lane = threadIdx.x & 63;
+    const int waves = SCHUR_THREADS / 64;
+    for (int p = blockIdx.x * waves + (threadIdx.x >> 6); p < P; p += gridDim.x * waves) {
+        double inv[9];
+        bool dead;
+        damped_point_inverse(Hpp + 9 * (int64_t)p, lambda, inv, dead);
+        if (first && lane < 9) Dpinv[9 * (int64_t)p + lane] = inv[lane];
+        if (dead) continue;  // no Jacobian rows: every Hcp block of this landmark is zero
+        const int o0 = pptr[p], k = pptr[p + 1] - o0;
+        const double *gp = g + 6 * (int64_t)F + 3 * (int64_t)p;
+        const double u0 = inv[0] * gp[0] + inv[1] * gp[1] + inv[2] * gp[2];
+        const double u1 = inv[3] * gp[0] + inv[4] * gp[1] + inv[5] * gp[2];
+        const double u2 = inv[6] * gp[0] + inv[7] * gp[1] + inv[8] * gp[2];
+        for (int t0 = 0; t0 < 6 * k; t0 += 64) {
+            const int t = t0 + lane;
+            const bool on = t < 6 * k;
+            const int b = on ? t / 6 : 0, j = on ? t - 6 * b : 0;
+            const int ob = pobs[o0 + b];
+            const double *y = Hcp + 18 * (int64_t)ob + 3 * j;
+            const double y0 = y[0], y1 = y[1], y2 = y[2];
+            const int cb = cam[ob], col = 6 * cb + j;
+            if (first && on) unsafeAtomicAdd(rhs + col, y0 * u0 + y1 * u1 + y2 * u2);
+            if (__ballot(on && cb < c1) == 0) continue;         // none of these columns reaches the strip
+            const double z0 = inv[0] * y0 + inv[1] * y1 + inv[2] * y2;
+            const double z1 = inv[3] * y0 + inv[4] * y1 + inv[5] * y2;
+            const double z2 = inv[6] * y0 + inv[7] * y1 + inv[8] * y2;
+            for (int a0 = 0; a0 < k; a0 += 64) {
+                const int na = min(64, k - a0);
+                const int my_oa = lane < na ? pobs[o0 + a0 + lane] : 0;
+                const int my_ca = lane < na ? cam[my_oa] : 0;
+                for (int a = 0; a < na; ++a) {
+                    const int ca = __builtin_amdgcn_readlane(my_ca, a);
+                    if (ca < c0 || ca >= c1) continue;               // wave-uniform: another strip's rows
+                    const int oa = __builtin_amdgcn_readlane(my_oa, a);
+                    const double *x = Hcp + 18 * (int64_t)oa;
+                    double *dst = sl + (size_t)(6 * (ca - c0)) * cols + col - colbase;
+                    if (!on || ca < cb) continue;                    // above the diagonal: not formed
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const double v = x[3 * i] * z0 + x[3 * i + 1] * z1 + x[3 * i + 2] * z2;
+                        if (v != 0.0 && (ca > cb || i >= j)) unsafeAtomicAdd(dst + (size_t)i * cols, -v);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * cols; i += SCHUR_THREADS) {
+        const double v = sl[i];
+        if (v != 0.0) {
+            const int r = i / cols, c = i - r * cols;
+            unsafeAtomicAdd(S + (size_t)(6 * c0 + r) * n + colbase + c, v);
+        }
     }
 }
 
@@ -1070,14 +1158,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, d
 // reaches back to its 20th-last keyframe and takes every frame since), still one workgroup, but blocked: a step
 // of ba_solve_kernel<false> touches the whole trailing matrix in global memory once per column and waits for it, 6F
 // times.  Here W columns at a time are staged in LDS as a panel (column-major: pan[c * ld + r] = A[k0 + r][k0 + c],
-// the right-hand side as the last row), factorised there with one barrier per column, written back, and applied to
-// the trailing matrix in one pass: A[i][j] -= sum_c (pan[i][c] / d_c) pan[j][c], a thread owning 4 x 4 tiles whose
-// operands it reads as 32-byte runs of the panel.  The back-substitution is blocked the same way: W rows of L^T at a
-// time come in with coalesced reads, the W x W triangle is solved in LDS, the rest of the vector is updated in one
+// the right-hand side as the last row): the panel's own triangle is factorised in registers, every row
+// below it then follows from that triangle alone, a row per thread, and the panel is applied to
+// the trailing matrix in one pass on the matrix cores: A[i][j] -= sum_c (pan[i][c] / d_c) pan[j][c].  The back-substitution is blocked the same way: W rows of L^T at a
+// time come in with coalesced reads, the W x W triangle is solved by one wave, the rest of the vector is updated in one
 // pass.  flag[0] = 1 on success, 0 when a pivot is not positive.
-#define SOLVEB_THREADS 1024
-#define SOLVEB_MAX_W 12
-__global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n, int F, int W, double *__restrict__ A,
+#define SOLVEB_THREADS 512
+typedef double vo_d4 __attribute__((ext_vector_type(4)));
+// the value lane l (the same for the whole wave) holds, whatever lanes are active
+__device__ __forceinline__ double lane_read(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+#define SOLVEB_MAX_W 16
+// block number -> (row, column) of a 32 x 32 block on or below the diagonal, rows first
+__device__ __forceinline__ void solveb_block_of(int blk, int &bi, int &bj)
+{
+    bi = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+    while (bi * (bi + 1) / 2 > blk) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+    bj = blk - bi * (bi + 1) / 2;
+}
+// a block of the trailing matrix (rows up to n: row n is the right-hand side b) in the result layout of the f64 product
+__device__ __forceinline__ void solveb_read_block(const double *A, const double *b, int n, int t0, int bi, int bj, int l4, int l15,
+                                                  double (&dst)[2][2][4])
+{
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = t0 + 32 * bi + 16 * a + l4 + 4 * e, j = t0 + 32 * bj + 16 * q + l15;
+                const bool ok = i <= n && j < n && j <= i;
+                dst[a][q][e] = ok ? (i < n ? A[(size_t)i * n + j] : b[j]) : 0.0;
+            }
+}
+__global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n, int F, int first, int W, double *__restrict__ A,
                                                                           double *__restrict__ b, const double *__restrict__ Hcc,
                                                                           const double *__restrict__ g, double lambda,
                                                                           double *__restrict__ dc, int *__restrict__ flag)
@@ -1105,74 +1223,139 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
         A[at] = dead ? v : A[at] + v;
     }
     for (int i = tid; i < n; i += SOLVEB_THREADS) b[i] -= g[i];
+    // rows and columns below `first` belong to cameras without unknowns: identity there, nothing to eliminate
+    for (int i = tid; i < first; i += SOLVEB_THREADS) dinv[i] = 1.0;
     __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += W) {
+    const int lane = tid & 63;
+    for (int k0 = first; k0 < n; k0 += W) {
         const int w = min(W, n - k0), rows = n - k0 + 1;
-        // panel in: rows k0 .. n-1 of columns k0 .. k0+w-1 (lower triangle), then the right-hand side
-        for (int e = tid; e < rows * w; e += SOLVEB_THREADS) {
-            const int r = e / w, c = e - r * w, i = k0 + r;
-            pan[c * ld + r] = i < n ? (c <= r ? A[(size_t)i * n + k0 + c] : 0.0) : b[k0 + c];
+        // The panel's own w x w triangle, a row per lane in registers.  Every wave factorises it for itself: the
+        // rows below then take its entries by lane reads, with no barrier and no trip through LDS in between.
+        double tv[SOLVEB_MAX_W], idr[SOLVEB_MAX_W], v[SOLVEB_MAX_W];
+#pragma unroll
+        for (int c = 0; c < SOLVEB_MAX_W; ++c) tv[c] = (lane < w && c <= lane) ? A[(size_t)(k0 + lane) * n + k0 + c] : 0.0;
+        // this thread's first row below the triangle (the right-hand side is the last row), read while the triangle is worked on
+        int r = w + tid;
+        double *src = r < rows ? (k0 + r < n ? A + (size_t)(k0 + r) * n + k0 : b + k0) : nullptr;
+        if (src) {
+#pragma unroll
+            for (int c = 0; c < SOLVEB_MAX_W; ++c) v[c] = c < w ? src[c] : 0.0;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < SOLVEB_MAX_W; ++c) {
+            idr[c] = 0.0;
+            if (c < w && !bad) {
+                const double d = lane_read(tv[c], c);
+                if (!(d > 0.0)) bad = true;
+                else {
+                    const double id = 1.0 / d;
+                    idr[c] = id;
+                    const double f = tv[c] * id;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < SOLVEB_MAX_W; ++c2) {
+                        const double pv = lane_read(tv[c], c2);          // row c2's entry of column c
+                        if (c2 <= lane) tv[c2] -= f * pv;
+                    }
+                }
+            }
+        }
+        if (bad) {                   // the same in every wave
+            fail = true;
+            break;
+        }
+        if (tid < w) {
+#pragma unroll
+            for (int c = 0; c < SOLVEB_MAX_W; ++c) {
+                if (c == tid) dinv[k0 + c] = idr[c];
+                if (c <= tid) A[(size_t)(k0 + tid) * n + k0 + c] = tv[c];
+            }
+        }
+        // entry c of a row takes the row's earlier entries and the triangle only (the factor's columns stay
+        // unscaled: c_ik = L_ik d_k)
+        while (src) {
+            double f[SOLVEB_MAX_W];
+#pragma unroll
+            for (int c = 0; c < SOLVEB_MAX_W; ++c) {
+                if (c < w) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) acc -= f[q] * lane_read(tv[q], c);
+                    f[c] = acc * idr[c];
+                    src[c] = acc;
+                    pan[c * ld + r] = acc;
+                }
+            }
+            r += SOLVEB_THREADS;
+            src = r < rows ? (k0 + r < n ? A + (size_t)(k0 + r) * n + k0 : b + k0) : nullptr;
+            if (src) {
+#pragma unroll
+                for (int c = 0; c < SOLVEB_MAX_W; ++c) v[c] = c < w ? src[c] : 0.0;
+            }
         }
         __syncthreads();
-        for (int c = 0; c < w; ++c) {
-            const double d = pan[c * ld + c];           // final since the previous barrier; same in every thread
-            if (!(d > 0.0)) {
-                fail = true;
-                break;
-            }
-            const double id = 1.0 / d;
-            if (tid == 0) dinv[k0 + c] = id;
-            const int nr = rows - c - 1, nc = w - c - 1;
-            for (int e = tid; e < nr * nc; e += SOLVEB_THREADS) {
-                const int c2 = c + 1 + e / nr, r = c + 1 + (e - (e / nr) * nr);
-                if (c2 <= r) pan[c2 * ld + r] -= pan[c * ld + r] * id * pan[c * ld + c2];
-            }
-            __syncthreads();
-        }
-        if (fail) break;
-        // panel out (the factor's columns stay unscaled: c_ik = L_ik d_k)
-        for (int e = tid; e < rows * w; e += SOLVEB_THREADS) {
-            const int r = e / w, c = e - r * w, i = k0 + r;
-            if (i < n) { if (c <= r) A[(size_t)i * n + k0 + c] = pan[c * ld + r]; }
-            else b[k0 + c] = pan[c * ld + r];
-        }
-        // trailing update in 4 x 4 tiles: rows t0 + 4 ti .. (matrix rows and the right-hand side), columns t0 + 4 tj ..
+        // Trailing update on the matrix cores: a wave takes 32 x 32 blocks on or below the diagonal as 2 x 2 products of
+        // v_mfma_f64_16x16x4_f64 (operands: lane l holds row l & 15 of the panel at column 4 s + (l >> 4) of step s;
+        // results: column l & 15, rows (l >> 4) + 4 e), the rows' side scaled by -1/d so the sum comes out negative
+        // and is added to the block read at the start.  Rows run over the matrix rows and the right-hand side.
         const int t0 = k0 + w, m = n - t0;
         if (m > 0) {
-            const int tr = (m + 1 + 3) / 4, tc = (m + 3) / 4;
-            for (int t = tid; t < tr * tc; t += SOLVEB_THREADS) {
-                const int ti = t / tc, tj = t - ti * tc;
-                if (4 * tj > 4 * ti + 3) continue;                  // wholly above the diagonal
-                double acc[4][4];
+            const int nb = (m + 1 + 31) / 32, nblk = nb * (nb + 1) / 2, l15 = lane & 15, l4 = lane >> 4;
+            // the block a wave takes next is read while the current one is computed: one CU alone has too few
+            // reads in flight otherwise, and every block would wait out its own trip to the L2
+            int blk = tid >> 6, bi = 0, bj = 0;
+            double cur[2][2][4], nxt[2][2][4];
+            if (blk < nblk) {
+                solveb_block_of(blk, bi, bj);
+                solveb_read_block(A, b, n, t0, bi, bj, l4, l15, cur);
+            }
+            while (blk < nblk) {
+                const int blk2 = blk + SOLVEB_THREADS / 64;
+                int bi2 = 0, bj2 = 0;
+                if (blk2 < nblk) {
+                    solveb_block_of(blk2, bi2, bj2);
+                    solveb_read_block(A, b, n, t0, bi2, bj2, l4, l15, nxt);
+                }
+                vo_d4 acc[2][2];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
-                const int ri = w + 4 * ti, rj = w + 4 * tj;           // panel rows of the tile's rows / columns
-                for (int c = 0; c < w; ++c) {
-                    const double id = dinv[k0 + c];
-                    double fa[4], fb[4];
+                    for (int q = 0; q < 2; ++q) acc[a][q] = vo_d4{0.0, 0.0, 0.0, 0.0};
+                for (int kc = 0; kc < w; kc += 4) {
+                    const int k = kc + l4;
+                    const bool kok = k < w;
+                    const double nid = kok ? -dinv[k0 + k] : 0.0;
+                    double fa[2], fb[2];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        fa[a] = ri + a < rows ? pan[c * ld + ri + a] * id : 0.0;
-                        fb[a] = rj + a < rows - 1 ? pan[c * ld + rj + a] : 0.0;
+                    for (int a = 0; a < 2; ++a) {
+                        const int ra = w + 32 * bi + 16 * a + l15, rb = w + 32 * bj + 16 * a + l15;
+                        fa[a] = (kok && ra < rows) ? pan[k * ld + ra] * nid : 0.0;
+                        fb[a] = (kok && rb < rows - 1) ? pan[k * ld + rb] : 0.0;
                     }
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[a][q] += fa[a] * fb[q];
+                        for (int q = 0; q < 2; ++q)
+                            if (!(bi == bj && q > a))              // wholly above the diagonal
+                                acc[a][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[q], acc[a][q], 0, 0, 0);
                 }
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int i = t0 + 4 * ti + a;
-                    if (i > n) continue;
-                    double *row = i < n ? A + (size_t)i * n : b;
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j = t0 + 4 * tj + q;
-                        if (j < n && j <= i) row[j] -= acc[a][q];
-                    }
-                }
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = t0 + 32 * bi + 16 * a + l4 + 4 * e, j = t0 + 32 * bj + 16 * q + l15;
+                            if (i <= n && j < n && j <= i) {
+                                const double out = cur[a][q][e] + acc[a][q][e];
+                                if (i < n) A[(size_t)i * n + j] = out;
+                                else b[j] = out;
+                            }
+                            cur[a][q][e] = nxt[a][q][e];
+                        }
+                blk = blk2;
+                bi = bi2;
+                bj = bj2;
             }
         }
         __syncthreads();
@@ -1186,20 +1369,40 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
     // b holds z = L^-1 rhs; y = D^-1 z; L^T x = y, W rows of L^T at a time from the bottom
     for (int i = tid; i < n; i += SOLVEB_THREADS) bs[i] = b[i] * dinv[i];
     __syncthreads();
-    const int last = ((n - 1) / W) * W;
-    for (int k0 = last; k0 >= 0; k0 -= W) {
+    const int last = first < n ? first + ((n - 1 - first) / W) * W : -1;
+    for (int k0 = last; k0 >= first; k0 -= W) {
         const int w = min(W, n - k0);
-        // rows k0 .. k0+w-1 of the factor, scaled: pan[r * ld + i] = A[k0 + r][i] / d_i for i < k0 + r
-        for (int r = 0; r < w; ++r)
-            for (int i = tid; i < k0 + r; i += SOLVEB_THREADS) pan[r * ld + i] = A[(size_t)(k0 + r) * n + i] * dinv[i];
-        __syncthreads();
-        for (int r = w - 1; r >= 0; --r) {          // the block's own triangle
-            const double xk = bs[k0 + r];
-            if (tid == 0) xs[r] = xk;
-            if (tid < r) bs[k0 + tid] -= pan[r * ld + k0 + tid] * xk;
-            __syncthreads();
+        // rows k0 .. k0+w-1 of the factor, scaled: pan[r * ld + i] = A[k0 + r][i] / d_i for first <= i < k0 + r
+        // (four reads in flight per thread: one after the other, each would wait out its own trip to memory)
+        const int cols = k0 + w - 1 - first, total = w * cols;
+        for (int e0 = tid; e0 < total; e0 += 4 * SOLVEB_THREADS) {
+            double val[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * SOLVEB_THREADS, r = cols ? e / cols : 0, i = first + e - r * cols;
+                const bool ok = e < total && i < k0 + r;
+                at[u] = ok ? r * ld + i : -1;
+                val[u] = ok ? A[(size_t)(k0 + r) * n + i] * dinv[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) pan[at[u]] = val[u];
         }
-        for (int i = tid; i < k0; i += SOLVEB_THREADS) {
+        __syncthreads();
+        if (tid < 64) {                             // the block's own triangle: one wave, an unknown per lane
+            double bv = tid < w ? bs[k0 + tid] : 0.0;
+            for (int r = w - 1; r >= 0; --r) {
+                const double xk = __shfl(bv, r);
+                if (tid < r) bv -= pan[r * ld + k0 + tid] * xk;
+            }
+            if (tid < w) {
+                xs[tid] = bv;
+                bs[k0 + tid] = bv;
+            }
+        }
+        __syncthreads();
+        for (int i = first + tid; i < k0; i += SOLVEB_THREADS) {
             double v = bs[i];
             for (int r = 0; r < w; ++r) v -= pan[r * ld + i] * xs[r];
             bs[i] = v;
@@ -1328,7 +1531,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         sci = hci; spi = hpi;
     }
     int *cam32 = (int *)malloc(((size_t)O + 1) * 4), *pptr = (int *)calloc((size_t)P + 2, 4), *pobs = (int *)malloc(((size_t)O + 1) * 4);
-    int rc = VO_OK;
+    int rc = VO_OK, cam_first = 0;
     if (!cam32 || !pptr || !pobs) { rc = VO_ENOMEM; vo_set_error("vo_ba_create: out of host memory"); }
     for (int i = 0; rc == VO_OK && i < O; ++i) {
         if (sci[i] < 0 || sci[i] >= F || spi[i] < 0 || spi[i] >= P) {
@@ -1339,19 +1542,27 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
     }
     vo_ba *ba = nullptr;
     if (rc == VO_OK) {
-        for (int i = 0; i < O; ++i) { cam32[i] = (int)sci[i]; pptr[spi[i] + 1]++; }
+        // the lists hold the observations with Jacobian rows only (index >= obs_start): the others add nothing to
+        // the normal equations, and the cameras below the first one seen among them have no unknowns to solve for
+        cam_first = F;
+        for (int i = 0; i < O; ++i) {
+            cam32[i] = (int)sci[i];
+            if (i < obs_start) continue;
+            pptr[spi[i] + 1]++;
+            if (cam32[i] < cam_first) cam_first = cam32[i];
+        }
         for (int p = 0; p < P; ++p) pptr[p + 1] += pptr[p];
         int *fill = (int *)malloc(((size_t)P + 1) * 4);
         if (!fill) { rc = VO_ENOMEM; vo_set_error("vo_ba_create: out of host memory"); }
         else {
             memcpy(fill, pptr, ((size_t)P + 1) * 4);
-            for (int i = 0; i < O; ++i) pobs[fill[spi[i]]++] = i;
+            for (int i = obs_start < O ? obs_start : O; i < O; ++i) pobs[fill[spi[i]]++] = i;
             free(fill);
         }
     }
     if (rc == VO_OK) {
         ba = new vo_ba();
-        ba->ctx = ctx; ba->F = F; ba->P = P; ba->O = O; ba->n = 6 * F; ba->obs_start = obs_start;
+        ba->ctx = ctx; ba->F = F; ba->P = P; ba->O = O; ba->n = 6 * F; ba->obs_start = obs_start; ba->cam_first = cam_first;
         memcpy(ba->K.k, K, sizeof(ba->K.k));
         const size_t n = (size_t)ba->n, np_ = n + 3 * (size_t)P, Oz = (size_t)(O ? O : 1);
         // pool layout
@@ -1416,8 +1627,21 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
                     ba->solve_lds = lds;
                 }
                 (void)hipGetLastError();
-                const char *env = getenv("VO_BA_SOLVE");          // "columns": the column-at-a-time kernel (comparison runs, tests)
-                if (env && env[0] == 'c') ba->solve_w = 0;
+                // strips of the Schur complement: as many cameras' rows as fit in LDS beside nothing else
+                const size_t live = n - 6 * (size_t)cam_first;          // six rows of `live` doubles per camera
+                int scams = live ? (int)((150 * 1024) / (6 * live * 8)) : 0;
+                if (scams > F - cam_first) scams = F - cam_first;
+                const size_t slds = (size_t)6 * scams * live * 8;
+                if (scams >= 1 && hipFuncSetAttribute((const void *)ba_schur_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)slds) == hipSuccess) {
+                    ba->strip_cams = scams;
+                    ba->strip_lds = slds;
+                }
+                (void)hipGetLastError();
+                const char *env = getenv("VO_BA_SOLVE");          // "columns": the earlier kernels (comparison runs, tests)
+                if (env && env[0] == 'c') { ba->solve_w = 0; ba->strip_cams = 0; }
+                const char *env2 = getenv("VO_BA_SCHUR");         // "global": sums straight into global memory
+                if (env2 && env2[0] == 'g') ba->strip_cams = 0;
             }
         }
     }
@@ -1460,7 +1684,15 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(blocks), dim3(SCHUR_THREADS), ba->lds_bytes, ctx->stream, n, ba->P, ba->F,
                            ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
-    else
+    else if (ba->strip_cams) {
+        const int strips = (ba->F - ba->cam_first + ba->strip_cams - 1) / ba->strip_cams;
+        int slices = (ba->P + waves - 1) / waves;
+        const int want = (256 + strips - 1) / strips;            // about one workgroup per CU in all
+        if (slices > want) slices = want;
+        hipLaunchKernelGGL(ba_schur_strip_kernel, dim3(slices, strips), dim3(SCHUR_THREADS), ba->strip_lds, ctx->stream, n, ba->P,
+                           ba->F, ba->cam_first, ba->strip_cams, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
+                           ba->S, ba->rhs);
+    } else
         hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(blocks), dim3(SCHUR_THREADS), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
                            ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
     VO_HIP_CHECK(hipGetLastError());
@@ -1468,7 +1700,8 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
                            ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
     else if (ba->solve_w)
-        hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, ba->solve_w,
+        hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
+                           6 * ba->cam_first, ba->solve_w,
                            ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
     else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,

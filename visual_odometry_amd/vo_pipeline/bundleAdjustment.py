@@ -96,10 +96,14 @@ class BundleAdjustment:
         n_points = landmarks.shape[0]
         num_frames = M.shape[0]
         x0 = np.hstack((self._camera_params(M).ravel(), np.asarray(landmarks, np.float64).ravel()))
-        difference = self._fun(x0, num_frames, n_points, camera_indices, point_indices, keypoints) ** 2
-        difference = difference.reshape(-1, 2).sum(axis=1)
-        keep = ~(difference > params.BA_DISTANCE_TH)
-        return keypoints[keep], camera_indices[keep], point_indices[keep]
+        r = self._fun(x0, num_frames, n_points, camera_indices, point_indices, keypoints)
+        u, v = r[0::2], r[1::2]
+        difference = u * u + v * v
+        drop = difference > params.BA_DISTANCE_TH
+        if not drop.any():
+            return keypoints, camera_indices, point_indices
+        kept = np.flatnonzero(~drop)
+        return keypoints[kept], camera_indices[kept], point_indices[kept]
 
     # ---- solve ------------------------------------------------------------------
     def bundle_adjustment(self, M: np.ndarray, landmarks: np.ndarray, camera_indices: np.ndarray,
