@@ -9,9 +9,10 @@ from visual_odometry_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def numpy_lm_step(ne, x, F, P, ci, pi, lam):
+def numpy_lm_step(ne, x, F, P, ci, pi, lam, with_condition=False):
     """One damped step from the block normal equations: D = H + lam*diag(H) (+1e-12 on camera
-    diagonals), identity for blocks without Jacobian rows, Schur complement on the landmarks."""
+    diagonals), identity for blocks without Jacobian rows, Schur complement on the landmarks.
+    with_condition: also the 2-norm condition number of the reduced system."""
     Hcc, Hpp, Hcp, g = ne["Hcc"], ne["Hpp"], ne["Hcp"], ne["g"]
     gc, gp = g[:6 * F].reshape(F, 6), g[6 * F:].reshape(P, 3)
     Dc = Hcc + lam * np.einsum("fij,ij->fij", Hcc, np.eye(6)) + 1e-12 * np.eye(6)
@@ -34,6 +35,8 @@ def numpy_lm_step(ne, x, F, P, ci, pi, lam):
     np.subtract.at(back, pi, np.einsum("oji,oj->oi", Hcp, dc[ci]))
     dp = np.einsum("pij,pj->pi", Dp_inv, back)
     dp[dead_p] = 0
+    if with_condition:
+        return x + np.hstack([dc.ravel(), dp.ravel()]), float(np.linalg.cond(S))
     return x + np.hstack([dc.ravel(), dp.ravel()])
 
 
@@ -42,10 +45,12 @@ def _start(F, ci):
 
 
 # 6 cameras: reduced system in LDS; 16: LDS beyond the default 64 KB; 26 and more: reduced system kept in global memory
-# and factorised in panels (26: 13 full panels; 60: the size of the end-to-end run's windows; 101: a ragged last panel),
-# or column by column ("columns": the earlier kernel, kept for comparison)
+# and factorised in panels, one launch per panel (26: 8 panels; 60: the size of the end-to-end run's shorter windows;
+# 101: its longer ones, a ragged last panel), or by the kernels kept for comparison: all panels in one workgroup
+# ("blocked") and column by column ("columns")
 @pytest.mark.parametrize("F,P,vis,solve", [(6, 150, 0.7, ""), (16, 300, 0.5, ""), (26, 200, 0.4, ""), (26, 200, 0.4, "columns"),
-                                           (60, 400, 0.3, ""), (101, 600, 0.3, "")])
+                                           (26, 200, 0.4, "blocked"), (60, 400, 0.3, ""), (60, 400, 0.3, "blocked"),
+                                           (101, 600, 0.3, "")])
 def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis, solve, monkeypatch):
     from visual_odometry_amd import hip
     if solve:

@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 from visual_odometry_amd import hip, synth
 ctx = hip.Context(0)
 res = {}
-for F, P, vis in ((60, 8000, 0.4), (60, 20000, 0.25), (26, 3000, 0.5)):
+for F, P, vis in ((60, 8000, 0.4), (60, 20000, 0.25), (26, 3000, 0.5), (100, 16000, 0.09)):
     pb = synth.ba_problem(F=F, P=P, visibility=vis, seed=1, obs_noise=0.4)
     start = int(np.count_nonzero(pb["ci"] < int(F / 4) + 1))
     s = hip.BaSolver(ctx, F, P, pb["ci"], pb["pi"], pb["obs"].astype(np.float64), pb["K"], start)

@@ -23,7 +23,7 @@ def main():
     from visual_odometry_amd import hip, synth
     ctx = hip.Context(0)
     rng = np.random.default_rng(77)
-    worst_step = worst_cost = 0.0
+    worst_step = worst_cost = worst_ratio = 0.0
     steps = 0
     for seed in range(a.seeds):
         F = int(rng.choice([2, 3, 5, 8, 10, 13, 20, 23, 24, 30]))
@@ -40,7 +40,7 @@ def main():
             cost = solver.linearize(x)
             assert abs(cost - float(ne["cost"])) <= 1e-9 * float(ne["cost"]), ("cost", seed, rounds)
             lam = float(rng.choice([1e-4, 1e-2, 1.0, 100.0]))
-            want = numpy_lm_step(ne, x, F, P, ci, pi, lam)
+            want, cond = numpy_lm_step(ne, x, F, P, ci, pi, lam, with_condition=True)
             cost_new, solved = solver.try_step(lam)
             assert solved, ("not solved", seed, rounds, lam)
             got = solver.params(candidate=True)
@@ -51,12 +51,15 @@ def main():
             ref_cost = float(oracle.ba_residual(got, F, P, ci, pi, obs, K)[1])
             cdev = abs(cost_new - ref_cost) / ref_cost
             worst_step, worst_cost = max(worst_step, dev), max(worst_cost, float(cdev))
-            assert dev <= 1e-6 and cdev <= 1e-10, ("step", seed, rounds, F, P, lam, dev, cdev)
+            # two float64 solvers of one system agree to about its condition number times the rounding unit
+            tol = max(1e-6, 10 * np.finfo(np.float64).eps * cond)
+            worst_ratio = max(worst_ratio, dev / tol)
+            assert dev <= tol and cdev <= 1e-10, ("step", seed, rounds, F, P, lam, dev, cdev, cond)
             steps += 1
-            x = got
+            x = want      # the next round starts from the reference step: the cases do not depend on the build's rounding
         solver.close()
     print(json.dumps({"op": "ba_solver", "seeds": a.seeds, "trial_steps": steps, "max_step_dev_rel": worst_step,
-                      "max_cost_dev_rel": worst_cost}), flush=True)
+                      "max_step_dev_over_tolerance": worst_ratio, "max_cost_dev_rel": worst_cost}), flush=True)
 
 
 if __name__ == "__main__":

@@ -892,7 +892,10 @@ struct vo_ba {
     int solve_w = 0;       // panel width of the blocked solve of a system that is not (0: the column-at-a-time kernel)
     size_t solve_lds = 0;
     int cam_first = 0;     // cameras below this one have no observation with Jacobian rows
-    int strip_cams = 0;    // cameras per strip of the strip-wise Schur complement of such a system (0: global atomics)
+    bool panels = false;   // factorise with one launch per panel (ba_solve_panel_kernel)
+    double *Lf = nullptr, *zf = nullptr, *dinv = nullptr;      // its factor, eliminated right-hand side, 1 / pivots
+    int n_strips = 0;    // strips of the strip-wise Schur complement of such a system (0: global atomics)
+    int strip_budget = 0;  // doubles of LDS a strip may take
     size_t strip_lds = 0;
 };
 
@@ -999,13 +1002,29 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
 
 
 // The Schur complement of a reduced system too large for one LDS copy (more than 23 cameras): the system is cut into
-// strips of `sc` cameras' rows, and a workgroup sums one strip's share of its landmarks in LDS -- the same per-landmark
+// strips of cameras' rows (ba_strip_bounds), and a workgroup sums one strip's share of its landmarks in LDS -- the same per-landmark
 // work as ba_schur_kernel, with the row blocks outside the strip skipped -- before adding it to global memory once.
 // blockIdx.y = strip, blockIdx.x = slice of the landmarks.  With the whole system in global memory every one of the
 // ~36 k^2 / 2 entries of a landmark seen k times is a float64 atomic on L2 (0.54 ms at 60 cameras and 20 000 landmarks);
 // here those land in LDS, and global memory sees one add per non-zero entry of a strip and workgroup.
 // Strip 0's workgroups also form Dp^-1 and the right-hand side.
-__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, int P, int F, int cam_first, int sc, const int *__restrict__ pptr,
+// Strip `want` of the cameras cam_first .. F-1: each strip takes as many cameras as keep its rows, from the column of
+// cam_first up to its own diagonal blocks, within `budget` doubles -- early strips are short in columns and so tall in
+// rows, and all hold about the same number of entries.  Returns false past the last strip.
+__host__ __device__ static inline bool ba_strip_bounds(int cam_first, int F, int budget, int want, int &c0, int &c1)
+{
+    c0 = cam_first;
+    for (int s = 0; c0 < F; ++s) {
+        int h = 1;
+        while (c0 + h < F && 36 * (h + 1) * (c0 + h + 1 - cam_first) <= budget) ++h;
+        c1 = c0 + h;
+        if (s == want) return true;
+        c0 = c1;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, int P, int F, int cam_first, int budget, const int *__restrict__ pptr,
                                                                        const int *__restrict__ pobs, const int *__restrict__ cam,
                                                                        const double *__restrict__ Hpp, const double *__restrict__ Hcp,
                                                                        const double *__restrict__ g, double lambda,
@@ -1013,7 +1032,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, in
                                                                        double *__restrict__ rhs)
 {
     extern __shared__ double sl[];
-    const int c0 = cam_first + blockIdx.y * sc, c1 = min(F, c0 + sc);      // cameras of this strip
+    int c0, c1;                                                            // cameras of this strip
+    if (!ba_strip_bounds(cam_first, F, budget, blockIdx.y, c0, c1)) return;
     // only columns from the first camera with unknowns up to the strip's own diagonal blocks are needed
     const int colbase = 6 * cam_first, rows = 6 * (c1 - c0), cols = 6 * c1 - colbase;
     for (int i = threadIdx.x; i < rows * cols; i += SCHUR_THREADS) sl[i] = 0.0;
@@ -1195,16 +1215,201 @@ __device__ __forceinline__ void solveb_read_block(const double *A, const double 
                 dst[a][q][e] = ok ? (i < n ? A[(size_t)i * n + j] : b[j]) : 0.0;
             }
 }
+// A barrier between phases that exchange data through LDS only: waits for this wave's LDS traffic, not for global
+// reads still in flight (__syncthreads would wait those out too, and with them any prefetch).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// 1 / d for a pivot: the hardware's estimate and two Newton steps (full precision for the normal values a
+// positive pivot takes; the division it replaces is several times as long a chain).
+__device__ __forceinline__ double fast_reciprocal(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+#define PANEL_MAX_W 32       // columns per launch of ba_solve_panel_kernel
+// LDL^T of a w x w triangle held a row per lane (tv[c] = entry c of row `lane`, c <= lane), columns left unscaled;
+// idr[c] = 1 / d_c.  Every lane runs the same steps, the pivot row's entries come by lane reads.  False when a
+// pivot is not positive.
+__device__ __forceinline__ bool solveb_triangle(double (&tv)[SOLVEB_MAX_W], double (&idr)[SOLVEB_MAX_W], int w, int lane)
+{
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < SOLVEB_MAX_W; ++c) {
+        idr[c] = 0.0;
+        if (c < w && !bad) {
+            const double d = lane_read(tv[c], c);
+            if (!(d > 0.0)) bad = true;
+            else {
+                const double id = 1.0 / d;
+                idr[c] = id;
+                const double f = tv[c] * id;
+#pragma unroll
+                for (int c2 = c + 1; c2 < SOLVEB_MAX_W; ++c2) {
+                    const double pv = lane_read(tv[c], c2);          // row c2's entry of column c
+                    if (c2 <= lane) tv[c2] -= f * pv;
+                }
+            }
+        }
+    }
+    return !bad;
+}
+
+// The same factorisation spread over the chip, one launch per panel (ba_solve_prep_kernel first,
+// ba_solve_blocked_kernel in its back-substitution mode last).  A wave owns one 32 x 32 block on or below the
+// diagonal of the trailing matrix and needs no other wave: it factorises the panel's triangle for itself, brings
+// the panel entries of its block's 32 rows (lanes 0-31) and 32 columns (lanes 32-63) up to date from that triangle,
+// a row per lane, passes them through its own LDS tile into the operand layout of v_mfma_f64_16x16x4_f64 and
+// updates the block in place.  The panel's columns of A and entries of b are only read in a launch (the update
+// touches columns right of the panel), so no wave sees another's writes; the factor's columns go to Lf, the
+// eliminated right-hand side to zf and the pivots' reciprocals to dinv, each written by one owner: the wave of
+// block 0 for the triangle, the diagonal block of a row range for the rows below.  A pivot that is not positive
+// clears flag[0], and later launches return at once.
+__global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w, double *A, double *b, double *__restrict__ Lf,
+                                                            double *__restrict__ zf, double *__restrict__ dinv,
+                                                            int *__restrict__ flag)
+{
+    __shared__ double tile[PANEL_MAX_W * 64];
+    if (flag[0] == 0) return;
+    const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    const int t0 = k0 + w, m = n - t0;          // trailing rows 0 .. m (row m: the right-hand side), columns 0 .. m-1
+    int bi, bj;
+    solveb_block_of(blockIdx.x, bi, bj);
+    double tv[PANEL_MAX_W], v[PANEL_MAX_W];
+#pragma unroll
+    for (int c = 0; c < PANEL_MAX_W; ++c) tv[c] = (lane < w && c <= lane) ? A[(size_t)(k0 + lane) * n + k0 + c] : 0.0;
+    const int lr = lane < 32 ? 32 * bi + lane : 32 * bj + lane - 32;
+    const bool valid = lr <= m;
+    const int i = t0 + lr;
+    const double *src = i < n ? A + (size_t)i * n + k0 : b + k0;
+    // n, k0 and the first live column are even: a row's panel entries start on a 16-byte boundary
+    if (valid && ((n | k0) & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; c += 2) {
+            const double2 two = c + 1 < w ? *(const double2 *)(src + c) : double2{c < w ? src[c] : 0.0, 0.0};
+            v[c] = two.x;
+            v[c + 1] = two.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; ++c) v[c] = (valid && c < w) ? src[c] : 0.0;
+    }
+    double cur[2][2][4];
+    solveb_read_block(A, b, n, t0, bi, bj, l4, l15, cur);
+    // Entry c of every row -- the triangle's (tv, a row per lane) and this block's (v) -- follows from the row's
+    // earlier entries and row c of the triangle: x_c -= sum_q (x_q / d_q) T[c][q].  T[c][q] is final after step q
+    // and comes by a lane read that serves both; the columns stay unscaled (c_ik = L_ik d_k).
+    double ft[PANEL_MAX_W], f[PANEL_MAX_W];
+    bool bad = false;
+    // owners of what leaves the launch: block 0 for the triangle, the diagonal block of a row range for its rows
+    // (the factor's entries scaled, L_ik; the right-hand side as it is)
+    double *tri_out = blockIdx.x == 0 && lane < w ? Lf + (size_t)(k0 + lane) * n + k0 : nullptr;
+    double *row_out = bi == bj && lane < 32 && valid ? (i < n ? Lf + (size_t)i * n + k0 : zf + k0) : nullptr;
+#pragma unroll
+    for (int c = 0; c < PANEL_MAX_W; ++c) {
+        if (c < w) {
+            double at = tv[c], av = v[c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) {
+                const double t = lane_read(tv[q], c);
+                at -= ft[q] * t;
+                av -= f[q] * t;
+            }
+            tv[c] = at;
+            v[c] = av;
+            const double d = lane_read(at, c);
+            if (!(d > 0.0)) bad = true;
+            const double id = fast_reciprocal(d);
+            ft[c] = at * id;
+            f[c] = av * id;
+            if (tri_out && c < lane) tri_out[c] = ft[c];
+            if (row_out) row_out[c] = i < n ? f[c] : av;
+            if (blockIdx.x == 0 && lane == c) dinv[k0 + c] = id;
+            tile[c * 64 + lane] = lane < 32 ? -f[c] : av;       // rows' side scaled by -1/d: the product comes out negative
+        }
+    }
+    if (bad) {
+        if (blockIdx.x == 0 && lane == 0) flag[0] = 0;
+        return;
+    }
+    __syncthreads();
+    vo_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[a][q] = vo_d4{0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < w; kc += 4) {
+        const int k = kc + l4;
+        const bool kok = k < w;
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fa[a] = kok ? tile[k * 64 + 16 * a + l15] : 0.0;
+            fb[a] = kok ? tile[k * 64 + 32 + 16 * a + l15] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (!(bi == bj && q > a))              // wholly above the diagonal
+                    acc[a][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[q], acc[a][q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ri = t0 + 32 * bi + 16 * a + l4 + 4 * e, cj = t0 + 32 * bj + 16 * q + l15;
+                if (ri <= n && cj < n && cj <= ri) {
+                    const double out = cur[a][q][e] + acc[a][q][e];
+                    if (ri < n) A[(size_t)ri * n + cj] = out;
+                    else b[cj] = out;
+                }
+            }
+}
+
+// Before the panels: the damped camera blocks onto the diagonal of S (identity for a camera without unknowns),
+// rhs - g_c, unit pivots and a zero right-hand side below `first`, flag[0] = 1.
+__global__ __launch_bounds__(256) void ba_solve_prep_kernel(int n, int F, int first, double *__restrict__ A, double *__restrict__ b,
+                                                            const double *__restrict__ Hcc, const double *__restrict__ g,
+                                                            double lambda, double *__restrict__ zf, double *__restrict__ dinv,
+                                                            int *__restrict__ flag)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) flag[0] = 1;
+    if (t < F * 36) {
+        const int c = t / 36, e = t - c * 36, i = e / 6, j = e - i * 6;
+        double sabs = 0;
+        for (int k = 0; k < 36; ++k) sabs += fabs(Hcc[36 * (int64_t)c + k]);
+        const bool dead = sabs == 0;
+        double v = Hcc[t];
+        if (i == j) v += lambda * v + 1e-12;
+        if (dead) v = (i == j) ? 1.0 : 0.0;
+        const size_t at = (size_t)(6 * c + i) * n + 6 * c + j;
+        A[at] = dead ? v : A[at] + v;
+    }
+    if (t < n) b[t] -= g[t];
+    if (t < first) {
+        dinv[t] = 1.0;
+        zf[t] = 0.0;
+    }
+}
+
+// Forward part only: leaves the factor in A, the eliminated right-hand side in b and the pivots' reciprocals in
+// dinv_g for ba_backsolve_kernel; flag[0] = 0 when a pivot is not positive, else 1.
 __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n, int F, int first, int W, double *__restrict__ A,
                                                                           double *__restrict__ b, const double *__restrict__ Hcc,
                                                                           const double *__restrict__ g, double lambda,
-                                                                          double *__restrict__ dc, int *__restrict__ flag)
+                                                                          int *__restrict__ flag, double *__restrict__ dinv_g)
 {
     extern __shared__ double sl[];
     __shared__ unsigned char dead_cam[256];
-    __shared__ double xs[SOLVEB_MAX_W];
     const int ld = n + 1;                       // panel column length (rows k0 .. n, the last one the right-hand side)
-    double *pan = sl, *dinv = sl + (size_t)W * ld, *bs = dinv + n;
+    double *pan = sl, *dinv = sl + (size_t)W * ld;
     const int tid = threadIdx.x;
     bool fail = false;              // every thread sees the same pivots: uniform
     for (int c = tid; c < F; c += SOLVEB_THREADS) {
@@ -1241,26 +1446,7 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
 #pragma unroll
             for (int c = 0; c < SOLVEB_MAX_W; ++c) v[c] = c < w ? src[c] : 0.0;
         }
-        bool bad = false;
-#pragma unroll
-        for (int c = 0; c < SOLVEB_MAX_W; ++c) {
-            idr[c] = 0.0;
-            if (c < w && !bad) {
-                const double d = lane_read(tv[c], c);
-                if (!(d > 0.0)) bad = true;
-                else {
-                    const double id = 1.0 / d;
-                    idr[c] = id;
-                    const double f = tv[c] * id;
-#pragma unroll
-                    for (int c2 = c + 1; c2 < SOLVEB_MAX_W; ++c2) {
-                        const double pv = lane_read(tv[c], c2);          // row c2's entry of column c
-                        if (c2 <= lane) tv[c2] -= f * pv;
-                    }
-                }
-            }
-        }
-        if (bad) {                   // the same in every wave
+        if (!solveb_triangle(tv, idr, w, lane)) {                   // the same in every wave
             fail = true;
             break;
         }
@@ -1268,7 +1454,7 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
 #pragma unroll
             for (int c = 0; c < SOLVEB_MAX_W; ++c) {
                 if (c == tid) dinv[k0 + c] = idr[c];
-                if (c <= tid) A[(size_t)(k0 + tid) * n + k0 + c] = tv[c];
+                if (c < tid) A[(size_t)(k0 + tid) * n + k0 + c] = tv[c] * idr[c];      // scaled: L_ik
             }
         }
         // entry c of a row takes the row's earlier entries and the triangle only (the factor's columns stay
@@ -1282,7 +1468,7 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
 #pragma unroll
                     for (int q = 0; q < c; ++q) acc -= f[q] * lane_read(tv[q], c);
                     f[c] = acc * idr[c];
-                    src[c] = acc;
+                    src[c] = k0 + r < n ? f[c] : acc;        // the factor scaled (L_ik), the right-hand side as it is
                     pan[c * ld + r] = acc;
                 }
             }
@@ -1361,56 +1547,93 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
         __syncthreads();
     }
     __syncthreads();
-    if (fail) {
-        if (tid == 0) flag[0] = 0;
+    for (int i = tid; i < n; i += SOLVEB_THREADS) dinv_g[i] = dinv[i];
+    if (tid == 0) flag[0] = fail ? 0 : 1;
+}
+
+// Back-substitution for the blocked factorisations: A holds the factor L below the diagonal, b the eliminated right-hand side z = L^-1 rhs, dinv_g the pivots' reciprocals; y = D^-1 z, L^T x = y,
+// W rows of L^T at a time from the bottom: the rows come in with coalesced reads, the W x W triangle is solved by one
+// wave in registers, the rest of the vector is updated in one pass.  One workgroup.  dc = x, zero for cameras
+// without unknowns and when flag[0] says the factorisation failed.
+__global__ __launch_bounds__(SOLVEB_THREADS) void ba_backsolve_kernel(int n, int F, int first, int W, const double *__restrict__ A,
+                                                                      const double *__restrict__ b, const double *__restrict__ dinv_g,
+                                                                      const double *__restrict__ Hcc, double *__restrict__ dc,
+                                                                      const int *__restrict__ flag)
+{
+    extern __shared__ double sl[];
+    __shared__ unsigned char dead_cam[256];
+    __shared__ double xs[SOLVEB_MAX_W];
+    const int ld = n + 1;
+    double *pan = sl, *bs = sl + (size_t)W * ld;
+    const int tid = threadIdx.x;
+    if (flag[0] == 0) {
         for (int i = tid; i < n; i += SOLVEB_THREADS) dc[i] = 0.0;
         return;
     }
-    // b holds z = L^-1 rhs; y = D^-1 z; L^T x = y, W rows of L^T at a time from the bottom
-    for (int i = tid; i < n; i += SOLVEB_THREADS) bs[i] = b[i] * dinv[i];
+    for (int c = tid; c < F; c += SOLVEB_THREADS) {
+        double sabs = 0;
+        for (int k = 0; k < 36; ++k) sabs += fabs(Hcc[36 * (int64_t)c + k]);
+        dead_cam[c] = sabs == 0;
+    }
+    for (int i = tid; i < n; i += SOLVEB_THREADS) bs[i] = b[i] * dinv_g[i];
     __syncthreads();
     const int last = first < n ? first + ((n - 1 - first) / W) * W : -1;
+    // Rows k0 .. k0+w-1 of the factor, entries first <= i < k0 + r of row k0 + r: 32 threads to a row, each taking
+    // every 32nd entry.  They do not depend on the unknowns, so the next block's are read into registers while the
+    // current block is solved: a block then costs its barriers and arithmetic, not a trip to memory.
+    static_assert(SOLVEB_MAX_W * 32 <= SOLVEB_THREADS, "a row of the block per 32 threads");
+    constexpr int PF = 1536 / 32;
+    const int pr = tid >> 5, px = tid & 31;
+    double pf[PF];
+    auto fetch = [&](int kf) {
+        const int wf = min(W, n - kf), colsf = kf + wf - 1 - first;
+        // every read is made, wanted or not (the others are left out when the values go to LDS): a read under a
+        // condition makes the compiler wait for all earlier ones first.  A row's reads may run up to 31 entries past
+        // its diagonal, so past the end of the matrix by as much in the last row: the caller keeps that much readable.
+        const double *row = A + (size_t)(kf + min(pr, wf - 1)) * n + first + px;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (32 * u < colsf) pf[u] = row[32 * u];
+        }
+    };
+    if (last >= first) fetch(last);
     for (int k0 = last; k0 >= first; k0 -= W) {
         const int w = min(W, n - k0);
-        // rows k0 .. k0+w-1 of the factor, scaled: pan[r * ld + i] = A[k0 + r][i] / d_i for first <= i < k0 + r
-        // (four reads in flight per thread: one after the other, each would wait out its own trip to memory)
-        const int cols = k0 + w - 1 - first, total = w * cols;
-        for (int e0 = tid; e0 < total; e0 += 4 * SOLVEB_THREADS) {
-            double val[4];
-            int at[4];
+        // into LDS: pan[r * ld + i] = L[k0 + r][i]; what lands at or right of a row's diagonal is never read
+        const int cols = k0 + w - 1 - first;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * SOLVEB_THREADS, r = cols ? e / cols : 0, i = first + e - r * cols;
-                const bool ok = e < total && i < k0 + r;
-                at[u] = ok ? r * ld + i : -1;
-                val[u] = ok ? A[(size_t)(k0 + r) * n + i] * dinv[i] : 0.0;
+        for (int u = 0; u < PF; ++u) {
+            if (32 * u < cols) {
+                const int i = first + px + 32 * u;
+                if (pr < w && i < n) pan[pr * ld + i] = pf[u];
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (at[u] >= 0) pan[at[u]] = val[u];
         }
-        __syncthreads();
+        if (k0 - W >= first) fetch(k0 - W);
+        lds_barrier();
         if (tid < 64) {                             // the block's own triangle: one wave, an unknown per lane
             double bv = tid < w ? bs[k0 + tid] : 0.0;
-            for (int r = w - 1; r >= 0; --r) {
-                const double xk = __shfl(bv, r);
-                if (tid < r) bv -= pan[r * ld + k0 + tid] * xk;
-            }
+            double col[SOLVEB_MAX_W];               // this unknown's column of the triangle, read before the serial part
+#pragma unroll
+            for (int r = 0; r < SOLVEB_MAX_W; ++r) col[r] = (r < w && tid < r) ? pan[r * ld + k0 + tid] : 0.0;
+#pragma unroll
+            for (int r = SOLVEB_MAX_W - 1; r >= 0; --r)
+                if (r < w) bv -= col[r] * lane_read(bv, r);
             if (tid < w) {
                 xs[tid] = bv;
                 bs[k0 + tid] = bv;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = first + tid; i < k0; i += SOLVEB_THREADS) {
             double v = bs[i];
-            for (int r = 0; r < w; ++r) v -= pan[r * ld + i] * xs[r];
+#pragma unroll
+            for (int r = 0; r < SOLVEB_MAX_W; ++r)
+                if (r < w) v -= pan[r * ld + i] * xs[r];
             bs[i] = v;
         }
-        __syncthreads();
+        lds_barrier();
     }
     for (int i = tid; i < n; i += SOLVEB_THREADS) dc[i] = dead_cam[i / 6] ? 0.0 : bs[i];
-    if (tid == 0) flag[0] = 1;
 }
 
 // dp = Dp^-1 (-g_p - sum_obs Hcp^T dc[camera]); candidate = current + (dc, dp).
@@ -1570,7 +1793,8 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
         const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
                      o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take((size_t)BA_REPLICAS * F * 42 * 8),
-                     o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8);
+                     o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
+                     o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8);
         size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
         for (int s = 0; s < 2; ++s) {
             o_x[s] = take(np_ * 8); o_cost[s] = take(8); o_Hcc[s] = take((size_t)F * 288); o_Hpp[s] = take((size_t)P * 72);
@@ -1586,6 +1810,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
             ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
             ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
+            ba->Lf = (double *)(b + o_Lf); ba->zf = (double *)(b + o_zf); ba->dinv = (double *)(b + o_dinv);
             for (int s = 0; s < 2; ++s) {
                 ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
                 ba->Hpp[s] = (double *)(b + o_Hpp[s]); ba->Hcp[s] = (double *)(b + o_Hcp[s]); ba->g[s] = (double *)(b + o_g[s]);
@@ -1622,26 +1847,33 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
                 if (w > SOLVEB_MAX_W) w = SOLVEB_MAX_W;
                 const size_t lds = ((size_t)w * (n + 1) + 2 * (size_t)n) * 8;
                 if (w >= 4 && hipFuncSetAttribute((const void *)ba_solve_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)lds) == hipSuccess) {
+                                                  (int)lds) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)ba_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+                        hipSuccess) {
                     ba->solve_w = (int)w;
                     ba->solve_lds = lds;
                 }
                 (void)hipGetLastError();
                 // strips of the Schur complement: as many cameras' rows as fit in LDS beside nothing else
-                const size_t live = n - 6 * (size_t)cam_first;          // six rows of `live` doubles per camera
-                int scams = live ? (int)((150 * 1024) / (6 * live * 8)) : 0;
-                if (scams > F - cam_first) scams = F - cam_first;
-                const size_t slds = (size_t)6 * scams * live * 8;
-                if (scams >= 1 && hipFuncSetAttribute((const void *)ba_schur_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)slds) == hipSuccess) {
-                    ba->strip_cams = scams;
-                    ba->strip_lds = slds;
+                // strips of the Schur complement: LDS for one camera's rows over the whole live width at least
+                const size_t live = n - 6 * (size_t)cam_first;
+                size_t sbudget = 150 * 1024 / 8;
+                if (sbudget < 6 * live) sbudget = 0;
+                int strips = 0, sc0, sc1;
+                while (sbudget && ba_strip_bounds(cam_first, F, (int)sbudget, strips, sc0, sc1)) ++strips;
+                if (strips >= 1 && hipFuncSetAttribute((const void *)ba_schur_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)(sbudget * 8)) == hipSuccess) {
+                    ba->n_strips = strips;
+                    ba->strip_budget = (int)sbudget;
+                    ba->strip_lds = sbudget * 8;
                 }
                 (void)hipGetLastError();
-                const char *env = getenv("VO_BA_SOLVE");          // "columns": the earlier kernels (comparison runs, tests)
-                if (env && env[0] == 'c') { ba->solve_w = 0; ba->strip_cams = 0; }
+                ba->panels = ba->solve_w > 0;
+                const char *env = getenv("VO_BA_SOLVE");          // earlier kernels (comparison runs, tests): "columns", or
+                if (env && env[0] == 'c') { ba->solve_w = 0; ba->n_strips = 0; ba->panels = false; }
+                if (env && env[0] == 'b') ba->panels = false;     // "blocked": the blocked factorisation in one workgroup
                 const char *env2 = getenv("VO_BA_SCHUR");         // "global": sums straight into global memory
-                if (env2 && env2[0] == 'g') ba->strip_cams = 0;
+                if (env2 && env2[0] == 'g') ba->n_strips = 0;
             }
         }
     }
@@ -1684,13 +1916,13 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(blocks), dim3(SCHUR_THREADS), ba->lds_bytes, ctx->stream, n, ba->P, ba->F,
                            ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
-    else if (ba->strip_cams) {
-        const int strips = (ba->F - ba->cam_first + ba->strip_cams - 1) / ba->strip_cams;
+    else if (ba->n_strips) {
+        const int strips = ba->n_strips;
         int slices = (ba->P + waves - 1) / waves;
         const int want = (256 + strips - 1) / strips;            // about one workgroup per CU in all
         if (slices > want) slices = want;
         hipLaunchKernelGGL(ba_schur_strip_kernel, dim3(slices, strips), dim3(SCHUR_THREADS), ba->strip_lds, ctx->stream, n, ba->P,
-                           ba->F, ba->cam_first, ba->strip_cams, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
+                           ba->F, ba->cam_first, ba->strip_budget, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
                            ba->S, ba->rhs);
     } else
         hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(blocks), dim3(SCHUR_THREADS), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
@@ -1699,10 +1931,26 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
                            ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
-    else if (ba->solve_w)
+    else if (ba->panels) {
+        const int first = 6 * ba->cam_first, W = PANEL_MAX_W;
+        const int work = ba->F * 36 > n ? ba->F * 36 : n;
+        hipLaunchKernelGGL(ba_solve_prep_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, n, ba->F, first, ba->S, ba->rhs,
+                           ba->Hcc[c], ba->g[c], lambda, ba->zf, ba->dinv, ba->flag);
+        for (int k0 = first; k0 < n; k0 += W) {
+            const int w = n - k0 < W ? n - k0 : W, m = n - k0 - w, nb = (m + 1 + 31) / 32;
+            hipLaunchKernelGGL(ba_solve_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S, ba->rhs,
+                               ba->Lf, ba->zf, ba->dinv, ba->flag);
+        }
+        hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, first,
+                           ba->solve_w, (const double *)ba->Lf, (const double *)ba->zf, (const double *)ba->dinv, ba->Hcc[c], ba->dc,
+                           (const int *)ba->flag);
+    } else if (ba->solve_w) {
         hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
-                           6 * ba->cam_first, ba->solve_w,
-                           ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+                           6 * ba->cam_first, ba->solve_w, ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->flag, ba->dinv);
+        hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
+                           6 * ba->cam_first, ba->solve_w, (const double *)ba->S, (const double *)ba->rhs, (const double *)ba->dinv,
+                           ba->Hcc[c], ba->dc, (const int *)ba->flag);
+    }
     else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
                            ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
