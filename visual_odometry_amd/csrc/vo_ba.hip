@@ -20,6 +20,9 @@
 
 #define BA_THREADS 256
 #define BA_REPLICAS 16  // copies of the camera blocks that the per-wave atomics are spread over
+// Partial sums of the cost, chosen by workgroup: one float64 atomic per wave on a single address is served one at a
+// time (about 14 ns each: 0.7 ms at 50 000 waves, the whole time of a 3.2 M-observation launch)
+#define BA_COST_SLOTS 256
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_d(double v)
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
                                                         double *__restrict__ r, double *__restrict__ cost,
                                                         double *__restrict__ Hcc, double *__restrict__ Hpp,
                                                         double *__restrict__ Hcp, double *__restrict__ g,
-                                                        double *__restrict__ cam_rep, double *__restrict__ Jp_out = nullptr,
+                                                        double *__restrict__ cam_rep, double *__restrict__ cost_slots,
+                                                        double *__restrict__ Jp_out = nullptr,
                                                         const int *__restrict__ list_start = nullptr,
                                                         const int *__restrict__ list_slot = nullptr, int *__restrict__ list_obs = nullptr)
 {
@@ -154,9 +158,10 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
         for (int k = 0; k < 6; ++k) cam[k] = params[6 * c + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) X[k] = params[6 * (int64_t)F + 3 * p + k];
-        ob[0] = obs[2 * (int64_t)i]; ob[1] = obs[2 * (int64_t)i + 1];
+        const double2 o2 = *(const double2 *)(obs + 2 * (int64_t)i);
+        ob[0] = o2.x; ob[1] = o2.y;
         ba_obs<WITH_J>(cam, X, K, ob, rr, Jc, Jp);
-        r[2 * (int64_t)i] = rr[0]; r[2 * (int64_t)i + 1] = rr[1];
+        *(double2 *)(r + 2 * (int64_t)i) = double2{rr[0], rr[1]};
     } else if (valid) {
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
         r[2 * (int64_t)i] = qnan; r[2 * (int64_t)i + 1] = qnan;
@@ -164,8 +169,9 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
     }
     // cost: wave sum, one atomic per wave
     const double cs = wave_sum_d(rr[0] * rr[0] + rr[1] * rr[1]);
+    double *cost_at = cost_slots ? cost_slots + blockIdx.x % BA_COST_SLOTS : cost;   // slots: ba_cam_sum_kernel adds them up
     if (!WITH_J) {
-        if (lane == 63) unsafeAtomicAdd(cost, 0.5 * cs);
+        if (lane == 63) unsafeAtomicAdd(cost_at, 0.5 * cs);
         return;
     }
 
@@ -189,43 +195,50 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
         const long long c0 = __shfl((long long)c, first);
         const bool uniform_cam = __ballot(active && c != c0) == 0;
         if (uniform_cam) {
-            // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r: every lane parks its 27 terms in
-            // LDS (row per term, column per lane), 54 lanes each add up half a row, one shuffle joins
-            // the halves, and 27 lanes issue the atomics (mirroring the off-diagonal entries).
+            // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r, eight terms at a time: every lane parks its
+            // terms in LDS (row per term, column per lane), a lane adds up an eighth of one row, three shuffles
+            // join the eighths, and eight lanes issue the atomics (mirroring the off-diagonal entries).  Eight
+            // rows per wave rather than all 27 keep the workgroup at 16 KB of LDS: with 56 KB only two waves
+            // fitted a SIMD, and at many windows the kernel waited on memory with nothing else to run.
             if constexpr (WITH_J) {
-                __shared__ double red[BA_THREADS / 64][27][65];
+                __shared__ double red[BA_THREADS / 64][8][65];
                 double(*mine)[65] = red[threadIdx.x >> 6];
-                int e = 0;
+                constexpr int TA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+                constexpr int TB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+                const int v = lane & 7, seg = lane >> 3;
+                double *hc = rep + 42 * c0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
+                for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
-                    for (int b = a; b < 6; ++b) mine[e++][lane] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) mine[21 + a][lane] = Jc[a] * rr[0] + Jc[6 + a] * rr[1];
-                // the rows are read by other lanes of the same wavefront: only the LDS writes have to have
-                // landed (a wavefront-scope fence would also wait for the wave's global stores)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int v = lane % 27, half = lane / 27;   // lanes 54..63 repeat rows 0..9 (third "half" is ignored)
-                const double *row = &mine[v][(half & 1) * 32];
-                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-                for (int i = 0; i < 32; i += 4) { s0 += row[i]; s1 += row[i + 1]; s2 += row[i + 2]; s3 += row[i + 3]; }
-                const double part = (s0 + s1) + (s2 + s3);
-                const double other = __shfl_down(part, 27);
-                if (lane < 27) {
-                    const double tot = part + other;
-                    double *hc = rep + 42 * c0;
-                    // term index -> (a, b) of the upper triangle, row-major
-                    const int ta = lane < 6 ? 0 : lane < 11 ? 1 : lane < 15 ? 2 : lane < 18 ? 3 : lane < 20 ? 4 : 5;
-                    const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
-                    if (lane < 21) {
-                        const int tb = ta + (lane - first_of_row);
-                        unsafeAtomicAdd(hc + ta * 6 + tb, tot);
-                        if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, tot);
-                    } else {
-                        unsafeAtomicAdd(hc + 36 + (lane - 21), tot);
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = 8 * ch + k, et = e < 21 ? e : 0, eg = e < 21 ? 0 : (e < 27 ? e - 21 : 0);
+                        if (e < 21) mine[k][lane] = Jc[TA[et]] * Jc[TB[et]] + Jc[6 + TA[et]] * Jc[6 + TB[et]];
+                        else if (e < 27) mine[k][lane] = Jc[eg] * rr[0] + Jc[6 + eg] * rr[1];
                     }
+                    // the rows are read by other lanes of the same wavefront: only the LDS writes have to have
+                    // landed (a wavefront-scope fence would also wait for the wave's global stores)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    const double *row = &mine[v][seg * 8];
+                    double part = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
+                    part += __shfl_xor(part, 8);
+                    part += __shfl_xor(part, 16);
+                    part += __shfl_xor(part, 32);
+                    const int e = 8 * ch + v;
+                    if (seg == 0 && e < 27) {
+                        if (e < 21) {
+                            // term index -> (a, b) of the upper triangle, row-major
+                            const int ta = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+                            const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
+                            const int tb = ta + (e - first_of_row);
+                            unsafeAtomicAdd(hc + ta * 6 + tb, part);
+                            if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, part);
+                        } else {
+                            unsafeAtomicAdd(hc + 36 + (e - 21), part);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's reads are in before the next one's writes
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         } else if (active) {
@@ -240,16 +253,20 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
     }
 
     if (valid) {
-        double *hx = Hcp + 18 * (int64_t)i;
+        // an observation's block is 144 bytes at a multiple of 144: nine 16-byte stores rather than eighteen of 8
+        double hv[18];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) hx[a * 3 + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
+            for (int b = 0; b < 3; ++b) hv[a * 3 + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
+        double2 *hx = (double2 *)(Hcp + 18 * (int64_t)i);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hx[k] = double2{hv[2 * k], hv[2 * k + 1]};
     }
     if (GATHER) {
         if (valid) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) Jp_out[6 * (int64_t)i + a] = Jp[a];
+            for (int a = 0; a < 3; ++a) ((double2 *)(Jp_out + 6 * (int64_t)i))[a] = double2{Jp[2 * a], Jp[2 * a + 1]};
             // landmark-major observation lists built on the device: this observation's place in its landmark's list
             if (list_obs && ok) list_obs[list_start[p] + list_slot[i]] = i;
         }
@@ -263,15 +280,23 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
             unsafeAtomicAdd(gp + a, Jp[a] * rr[0] + Jp[3 + a] * rr[1]);
         }
     }
-    if (lane == 63) unsafeAtomicAdd(cost, 0.5 * cs);
+    if (lane == 63) unsafeAtomicAdd(cost_at, 0.5 * cs);
 }
 
 // Hcc[c] and g[6c..6c+5] = sum over the replicas filled by ba_kernel (overwrites both); with
 // Hpp given, the lower triangles of the landmark blocks are filled from the upper ones.
 __global__ __launch_bounds__(256) void ba_cam_sum_kernel(int F, const double *__restrict__ cam_rep, double *__restrict__ Hcc,
-                                                         double *__restrict__ g, int P, double *__restrict__ Hpp)
+                                                         double *__restrict__ g, int P, double *__restrict__ Hpp,
+                                                         const double *__restrict__ cost_slots, double *__restrict__ cost)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (cost_slots && t < 64) {                   // cost = sum of the slots (overwrites)
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < BA_COST_SLOTS / 64; ++k) s += cost_slots[t + 64 * k];
+        s = wave_sum_d(s);
+        if (t == 63) cost[0] = s;
+    }
     if (Hpp && t < P) {
         double *hp = Hpp + 9 * (int64_t)t;
         hp[3] = hp[1]; hp[6] = hp[2]; hp[7] = hp[5];
@@ -442,14 +467,20 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
         }
     }
     VO_HIP_CHECK(hipMemsetAsync(d_cost, 0, 8, ctx->stream));
-    double *d_rep = nullptr;
+    double *d_rep = nullptr, *d_slots = nullptr;
     const bool gather = WITH_J && O >= ba_gather_min_obs() && P > 0;
-    if (WITH_J) {
+    // few workgroups add their cost straight to the result; many go through the slots
+    const bool cost_slots = O > BA_COST_SLOTS * BA_THREADS;
+    if (WITH_J || cost_slots) {
         void *rp;
-        const size_t rep_bytes = (size_t)BA_REPLICAS * (F ? F : 1) * 42 * 8;
+        const size_t cam_bytes = WITH_J ? (size_t)BA_REPLICAS * (F ? F : 1) * 42 * 8 : 0;
+        const size_t rep_bytes = cam_bytes + (size_t)BA_COST_SLOTS * 8;
         if ((rc = vo_stage_reserve(ctx, 1, rep_bytes, &rp))) return rc;
         d_rep = (double *)rp;
+        if (cost_slots) d_slots = (double *)((char *)rp + cam_bytes);
         VO_HIP_CHECK(hipMemsetAsync(d_rep, 0, rep_bytes, ctx->stream));
+    }
+    if (WITH_J) {
         if (!gather) {
             if (P) VO_HIP_CHECK(hipMemsetAsync(d_Hpp, 0, (size_t)P * 72, ctx->stream));
             if (P) VO_HIP_CHECK(hipMemsetAsync(d_g + 6 * (size_t)F, 0, (size_t)P * 24, ctx->stream));
@@ -474,21 +505,27 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
         hipLaunchKernelGGL(ba_scan_finish_kernel, dim3(nblk), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_cnt, P, (const int *)d_bsum, d_start);
         const unsigned blocks = (unsigned)((O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL((ba_kernel<WITH_J, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, d_params, F, P, d_ci, d_pi, d_obs, O, Kv,
-                           obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep, d_Jp, (const int *)d_start, (const int *)d_slot, d_list);
+                           obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep, d_slots, d_Jp, (const int *)d_start, (const int *)d_slot, d_list);
         hipLaunchKernelGGL(ba_point_gather_ordered_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, P, F, (const int *)d_start,
                            (const int *)d_list, (const double *)d_Jp, (const double *)d_r, obs_start, d_Hpp, d_g);
-        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((F * 42 + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, 0, (double *)nullptr);
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((F * 42 + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, 0, (double *)nullptr,
+                           (const double *)d_slots, d_cost);
         VO_HIP_CHECK(hipGetLastError());
     } else {
     if (O) {
         const unsigned blocks = (unsigned)((O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL(ba_kernel<WITH_J>, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, d_params, F, P, d_ci, d_pi,
-                           d_obs, O, Kv, obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep);
+                           d_obs, O, Kv, obs_start, d_r, d_cost, d_Hcc, d_Hpp, d_Hcp, d_g, d_rep, d_slots);
         VO_HIP_CHECK(hipGetLastError());
     }
     if (WITH_J && (F || P)) {
         const int work = F * 42 > P ? F * 42 : P;
-        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, P, d_Hpp);
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, F, d_rep, d_Hcc, d_g, P, d_Hpp,
+                           (const double *)d_slots, d_cost);
+        VO_HIP_CHECK(hipGetLastError());
+    } else if (d_slots) {
+        hipLaunchKernelGGL(ba_cam_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, 0, d_rep, d_Hcc, d_g, 0, (double *)nullptr,
+                           (const double *)d_slots, d_cost);
         VO_HIP_CHECK(hipGetLastError());
     }
     }
@@ -1701,16 +1738,17 @@ static int ba_linearize_into(vo_ba *ba, int slot)
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
     VO_HIP_CHECK(hipMemsetAsync(ba->cost[slot], 0, 8, ctx->stream));
     (void)np_;
-    VO_HIP_CHECK(hipMemsetAsync(ba->cam_rep, 0, (size_t)BA_REPLICAS * ba->F * 42 * 8, ctx->stream));
+    const size_t cam_doubles = (size_t)BA_REPLICAS * ba->F * 42;
+    VO_HIP_CHECK(hipMemsetAsync(ba->cam_rep, 0, (cam_doubles + BA_COST_SLOTS) * 8, ctx->stream));
     if (ba->O) {
         const unsigned blocks = (unsigned)((ba->O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL((ba_kernel<true, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P,
                            ba->ci, ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot],
-                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->cam_rep, ba->Jp);
+                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->cam_rep, ba->cam_rep + cam_doubles, ba->Jp);
         VO_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((ba->F * 42 + 255) / 256), dim3(256), 0, ctx->stream, ba->F, ba->cam_rep,
-                       ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr);
+                       ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr, (const double *)(ba->cam_rep + cam_doubles), ba->cost[slot]);
     VO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
                        ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot]);
@@ -1792,7 +1830,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         size_t tot = 0;
         auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
         const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
-                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take((size_t)BA_REPLICAS * F * 42 * 8),
+                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
                      o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
                      o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8);
         size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
