@@ -1957,7 +1957,9 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     else if (ba->n_strips) {
         const int strips = ba->n_strips;
         int slices = (ba->P + waves - 1) / waves;
-        const int want = (256 + strips - 1) / strips;            // about one workgroup per CU in all
+        // about one workgroup per CU in all: the kernel runs at the rate of the CUs' float64 LDS atomics (about one
+        // lane every two cycles), so fewer workgroups are slower in proportion, whatever their flush saves
+        const int want = (256 + strips - 1) / strips;
         if (slices > want) slices = want;
         hipLaunchKernelGGL(ba_schur_strip_kernel, dim3(slices, strips), dim3(SCHUR_THREADS), ba->strip_lds, ctx->stream, n, ba->P,
                            ba->F, ba->cam_first, ba->strip_budget, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
