@@ -204,11 +204,18 @@ __global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__
 // A workgroup tests 64 x 4 pixels of one layer.  It first stages the 66 x 6 neighbourhood of the layer and of its two
 // neighbours in LDS with coalesced reads that are all in flight at once (testing straight from memory made every
 // wavefront wait for three dependent rounds of reads: 185 us at the finest octave of a 1241 x 376 frame).
+// Candidates and keypoints are appended to SIFT_LISTS lists, each with its own counter (SIFT_LIST_STRIDE ints apart, a
+// cache line each) and 1 / SIFT_LISTS of the buffer: appends through one counter are served one after the other
+// (about 14 ns each), which for tens of thousands of them was most of the time of the kernels that make them.
+#define SIFT_LISTS 64
+#define SIFT_LIST_STRIDE 16
 __global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restrict__ dog, size_t plane, int w, int h, int octave,
                                                           int threshold, SiftCand *__restrict__ cand, int *__restrict__ count,
                                                           int cap)
 {
     __shared__ float t[3][6][68];
+    __shared__ int s_found, s_base;
+    if (threadIdx.x == 0) s_found = 0;
     const int c0 = SIFT_IMG_BORDER + blockIdx.x * 64, r0 = SIFT_IMG_BORDER + blockIdx.y * 4;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = c0 + tx, r = r0 + ty;
@@ -238,17 +245,46 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restri
             found = (val > 0 && val >= hi) || (val < 0 && val <= lo);
         }
     }
-    // one atomic per wavefront
+    // one LDS atomic per wavefront, one global atomic per workgroup, on the list the workgroup's position picks
     const unsigned long long m = __ballot(found);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    const int lane = threadIdx.x & 63, leader = m ? __ffsll((long long)m) - 1 : 0;
     int base = 0;
-    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    if (m && lane == leader) base = atomicAdd(&s_found, __popcll(m));
     base = __shfl(base, leader);
+    __syncthreads();
+    const int list = (blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z + 23 * octave) & (SIFT_LISTS - 1), list_cap = cap / SIFT_LISTS;
+    if (threadIdx.x == 0 && s_found) s_base = atomicAdd(count + list * SIFT_LIST_STRIDE, s_found);
+    __syncthreads();
     if (found) {
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot < cap) cand[slot] = SiftCand{octave, layer, r, c};
+        const int slot = s_base + base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < list_cap) cand[(size_t)list * list_cap + slot] = SiftCand{octave, layer, r, c};
     }
+}
+
+// The keypoint lists put end to end: block b copies list b behind the lists before it; total[0] = the number of
+// keypoints, or cap + 1 when a list overflowed.
+__global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keypoint *__restrict__ lists, const int *__restrict__ counts,
+                                                             int cap, vo_sift_keypoint *__restrict__ joined, int *__restrict__ total)
+{
+    __shared__ int s_off, s_n;
+    const int list_cap = cap / SIFT_LISTS;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, raw = counts[lane * SIFT_LIST_STRIDE], mine = min(raw, list_cap);
+        int upto = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(upto, d);
+            if (lane >= d) upto += o;
+        }
+        const bool over = __ballot(raw > list_cap) != 0;
+        if (lane == (int)blockIdx.x) { s_off = upto - mine; s_n = mine; }
+        if (blockIdx.x == 0 && lane == 63) total[0] = over ? cap + 1 : upto;
+    }
+    __syncthreads();
+    const uint2 *src = (const uint2 *)(lists + (size_t)blockIdx.x * list_cap);
+    uint2 *dst = (uint2 *)(joined + s_off);
+    static_assert(sizeof(vo_sift_keypoint) % 8 == 0, "keypoints are copied 8 bytes at a time");
+    const int words = s_n * (int)(sizeof(vo_sift_keypoint) / 8);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
 }
 
 struct SiftOctaves {
@@ -268,9 +304,19 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict
     __shared__ int s_bin[SIFT_ORI_CHUNK];
     __shared__ float s_th[SIFT_ORI_HIST_BINS + 4];
     const int lane = threadIdx.x;
-    const int total = min(*n_cand, cand_cap);
-    if ((int)blockIdx.x >= total) return;
-    const SiftCand cd = cand[blockIdx.x];
+    // candidate number blockIdx.x of the lists taken one after the other
+    const int list_cap = cand_cap / SIFT_LISTS;
+    const int mine = min(n_cand[lane * SIFT_LIST_STRIDE], list_cap);
+    int upto = mine;                               // inclusive prefix over the 64 lists
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(upto, d);
+        if (lane >= d) upto += o;
+    }
+    const unsigned long long later = __ballot((int)blockIdx.x < upto);
+    if (later == 0) return;
+    const int list = __ffsll((long long)later) - 1;
+    const int within = (int)blockIdx.x - (__shfl(upto, list) - __shfl(mine, list));
+    const SiftCand cd = cand[(size_t)list * list_cap + within];
     const int octv = cd.octave, w = O.w[octv], h = O.h[octv], nl = O.layers;
     const size_t plane = (size_t)w * h;
     const float *dogs = pool + O.dog_off[octv];
@@ -377,8 +423,9 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict
         bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
         kp.angle = 360.f - (360.f / n) * bin;
         if (fabsf(kp.angle - 360.f) < SIFT_FLT_EPSILON) kp.angle = 0.f;
-        const int slot = atomicAdd(n_out, 1);
-        if (slot < out_cap) out[slot] = kp;
+        const int klist = blockIdx.x & (SIFT_LISTS - 1), klist_cap = out_cap / SIFT_LISTS;
+        const int slot = atomicAdd(n_out + klist * SIFT_LIST_STRIDE, 1);
+        if (slot < klist_cap) out[(size_t)klist * klist_cap + slot] = kp;
     }
 }
 
@@ -695,13 +742,17 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     const SiftOctaves &O = S.O;
 
     // candidates and raw keypoints: counters | candidates | keypoints (context slot 3)
+    // counters (candidate lists | keypoint lists | keypoint total) | candidates | keypoint lists | keypoints joined
     const int cand_cap = 1 << 19, kp_cap = 1 << 18;
+    const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64) * 4;
     void *p;
-    if ((rc = vo_stage_reserve(ctx, 3, 256 + (size_t)cand_cap * sizeof(SiftCand) + (size_t)kp_cap * sizeof(vo_sift_keypoint), &p))) return rc;
-    int *d_cnt = (int *)p;
-    SiftCand *d_cand = (SiftCand *)((char *)p + 256);
-    vo_sift_keypoint *d_kp = (vo_sift_keypoint *)((char *)p + 256 + (size_t)cand_cap * sizeof(SiftCand));
-    VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+    if ((rc = vo_stage_reserve(ctx, 3, cnt_bytes + (size_t)cand_cap * sizeof(SiftCand) + 2 * (size_t)kp_cap * sizeof(vo_sift_keypoint), &p)))
+        return rc;
+    int *d_cnt = (int *)p, *d_kcnt = d_cnt + SIFT_LISTS * SIFT_LIST_STRIDE, *d_ktotal = d_kcnt + SIFT_LISTS * SIFT_LIST_STRIDE;
+    SiftCand *d_cand = (SiftCand *)((char *)p + cnt_bytes);
+    vo_sift_keypoint *d_klists = (vo_sift_keypoint *)((char *)p + cnt_bytes + (size_t)cand_cap * sizeof(SiftCand));
+    vo_sift_keypoint *d_kp = d_klists + kp_cap;
+    VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
     const int threshold = (int)floor(0.5 * contrast_threshold / n_octave_layers * 255);
     for (int o = 0; o < O.n_oct; ++o) {
         const int ow = O.w[o], oh = O.h[o];
@@ -712,15 +763,28 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     }
     VO_HIP_CHECK(hipGetLastError());
     int h_cnt[2] = {0, 0};
-    VO_RESULT(ctx, h_cnt, d_cnt, 4);
-    VO_RESULTS_FINISH(ctx);
-    if (h_cnt[0] > cand_cap) { vo_set_error("vo_sift_detect_compute: %d scale-space extrema exceed the candidate buffer (%d)", h_cnt[0], cand_cap); return VO_ESTATE; }
+    {
+        int h_lists[SIFT_LISTS * SIFT_LIST_STRIDE];
+        VO_RESULT(ctx, h_lists, d_cnt, sizeof(h_lists));
+        VO_RESULTS_FINISH(ctx);
+        for (int l = 0; l < SIFT_LISTS; ++l) {
+            const int n = h_lists[l * SIFT_LIST_STRIDE];
+            if (n > cand_cap / SIFT_LISTS) {
+                vo_set_error("vo_sift_detect_compute: %d scale-space extrema in one of %d lists exceed its share of the candidate buffer (%d)",
+                             n, SIFT_LISTS, cand_cap / SIFT_LISTS);
+                return VO_ESTATE;
+            }
+            h_cnt[0] += n;
+        }
+    }
     if (h_cnt[0] > 0) {
         hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
-                           (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp, d_cnt + 1, kp_cap);
+                           (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_klists, d_kcnt, kp_cap);
+        hipLaunchKernelGGL(sift_join_lists_kernel, dim3(SIFT_LISTS), dim3(256), 0, ctx->stream, (const vo_sift_keypoint *)d_klists,
+                           (const int *)d_kcnt, kp_cap, d_kp, d_ktotal);
         VO_HIP_CHECK(hipGetLastError());
     }
-    VO_RESULT(ctx, h_cnt + 1, d_cnt + 1, 4);
+    VO_RESULT(ctx, h_cnt + 1, d_ktotal, 4);
     VO_RESULTS_FINISH(ctx);
     if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
     std::vector<vo_sift_keypoint> kps((size_t)h_cnt[1]);
