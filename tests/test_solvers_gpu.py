@@ -137,7 +137,7 @@ def test_refine_pose_one_launch(oracle, ctx):
             step = np.linalg.solve(H + 1e-9 * np.trace(H) / 6 * np.eye(6), -g)
             prev, prev_cam = c, cam.copy()
             cam = cam + step
-            if np.abs(step).max() <= 1e-9 * max(1.0, np.abs(cam).max()):
+            if np.abs(step).max() <= 1e-5 * max(1.0, np.abs(cam).max()):
                 return cam, last          # converged: the step is taken, no pass to confirm it
         return cam, last
 

@@ -20,3 +20,5 @@ for it in (0, 1, 2, 3, 4, 10):
         t0 = time.perf_counter(); r = hip.refine_pose(ctx, Xd, xd, K, rv0, t, max_iters=it); ts.append(time.perf_counter() - t0)
     res[it] = round(float(np.median(ts) * 1e6), 1)
 print(json.dumps(res))
+poses = {it: np.hstack(hip.refine_pose(ctx, Xd, xd, K, rv0, t, max_iters=it)[:2]) for it in (0, 1, 2, 3, 4)}
+print(json.dumps({f"step{it}": float(np.abs(poses[it] - poses[it - 1]).max() / max(1.0, np.abs(poses[it]).max())) for it in (1, 2, 3, 4)}))

@@ -563,12 +563,16 @@ extern "C" int vo_ba_normal_eq(vo_ctx *ctx, const double *params, int F, int P, 
 // follows the RANSAC loop inside cv.solvePnPRansac (vo_pipeline/poseEstimation.py:61-69;
 // OpenCV refits with its own PnP solver, this minimises the same reprojection error).
 // One workgroup: every iteration sums the 6x6 normal equations over the selected
-// correspondences (DPP wave sums, then across waves in LDS), lane 0 solves the damped
-// system by Cholesky.  Stops when the cost rises (the previous pose is returned), when it stops
-// improving by more than 1e-10 relative, when a step falls below 1e-9 of the pose (that step is
+// correspondences (every lane's partial sums through LDS, eight lanes per sum), and every
+// lane solves the damped system for itself by LDL^T.  Stops when the cost rises (the previous pose is returned), when it stops
+// improving by more than 1e-10 relative, when a step falls below 1e-5 of the pose (that step is
 // taken; the cost reported is the one before it), or after max_iters.
 // ---------------------------------------------------------------------------
-#define REFINE_THREADS 512
+#define REFINE_THREADS 256
+#define REFINE_STEP_TOL 1e-5
+#define REFINE_RED 8          // lanes per sum in the reduction (28 * REFINE_RED <= REFINE_THREADS)
+#define REFINE_PITCH (REFINE_THREADS + REFINE_RED)
+#define REFINE_CACHED 4096   // correspondences kept in LDS (20 bytes + a flag each, beside the partial sums)
 struct Pose6 { double v[6]; };
 
 // Rotation vector of a rotation matrix (row-major 3x3 inside a 3x4 [R|t], row pitch 4) via the unit quaternion,
@@ -613,7 +617,9 @@ __device__ static void rotation_and_derivatives(const double *w, double *R, doub
     }
     double s, c;
     sincos(th, &s, &c);
-    const double v[3] = {w[0] / th, w[1] / th, w[2] / th};
+    // two reciprocals instead of twelve divisions: this chain runs on every lane before the point loop can start
+    const double ith = 1.0 / th, ith2 = ith * ith;
+    const double v[3] = {w[0] * ith, w[1] * ith, w[2] * ith};
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -624,8 +630,8 @@ __device__ static void rotation_and_derivatives(const double *w, double *R, doub
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double u[3] = {(k == 0) - R[k], (k == 1) - R[3 + k], (k == 2) - R[6 + k]};      // (I - R) e_k
-        const double m[3] = {(w[k] * w[0] + (w[1] * u[2] - w[2] * u[1])) / th2, (w[k] * w[1] + (w[2] * u[0] - w[0] * u[2])) / th2,
-                             (w[k] * w[2] + (w[0] * u[1] - w[1] * u[0])) / th2};
+        const double m[3] = {(w[k] * w[0] + (w[1] * u[2] - w[2] * u[1])) * ith2, (w[k] * w[1] + (w[2] * u[0] - w[0] * u[2])) * ith2,
+                             (w[k] * w[2] + (w[0] * u[1] - w[1] * u[0])) * ith2};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {           // column j of [m]x R = m x (column j of R)
             dR[k][j] = m[1] * R[6 + j] - m[2] * R[3 + j];
@@ -646,11 +652,14 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                                                                      const int *__restrict__ sel_dev, const int *__restrict__ n_dev,
                                                                      const int *__restrict__ mask_row)
 {
-    __shared__ double red[REFINE_THREADS / 64][28];
+    // every lane's 28 partial sums, one row per sum: consecutive lanes of a row are consecutive doubles, and a row starts
+    // REFINE_RED doubles further into the 256-byte LDS line than the row before it, so the rows that the reducing lanes of
+    // a half-wavefront read at once fall on different banks
+    __shared__ double part[28][REFINE_PITCH];
     __shared__ double tot[28];
-    __shared__ double cam_s[6];
-    __shared__ int stop_s;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ float pts[5][REFINE_CACHED];
+    __shared__ uint8_t pts_sel[REFINE_CACHED];
+    const int tid = threadIdx.x;
     if (n_dev) n = *n_dev;
     if (Rt_src) {
         if (sel_dev) sel = *sel_dev;
@@ -658,21 +667,38 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
             if (tid < 8) out[tid] = __builtin_nan("");
             return;
         }
-        if (tid == 0) {
-            const double *Rt = Rt_src + 12 * (int64_t)sel;
-            double rv[3];
-            rotvec_of_Rt(Rt, rv);
-            cam_s[0] = rv[0]; cam_s[1] = rv[1]; cam_s[2] = rv[2];
-            cam_s[3] = Rt[3]; cam_s[4] = Rt[7]; cam_s[5] = Rt[11];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 6; ++k) start.v[k] = cam_s[k];
-        __syncthreads();
+        // every lane converts the candidate for itself (same reads, same arithmetic): no hand-over through LDS
+        const double *Rt = Rt_src + 12 * (int64_t)sel;
+        rotvec_of_Rt(Rt, start.v);
+        start.v[3] = Rt[3]; start.v[4] = Rt[7]; start.v[5] = Rt[11];
     }
     double cam[6], prev_cam[6], prev_cost = __builtin_inf(), last_cost = __builtin_inf();
 #pragma unroll
     for (int k = 0; k < 6; ++k) { cam[k] = start.v[k]; prev_cam[k] = start.v[k]; }
+    // The first REFINE_CACHED correspondences are fetched once, all of a lane's reads in flight together, and kept in
+    // LDS with their selection flag: in the passes a lane's reads (row map, mask, landmark, pixel) are three
+    // dependent global-memory latencies per correspondence, which was half of the kernel's time.
+    const int n_cached = min(n, REFINE_CACHED);
+    for (int i0 = tid; i0 < n_cached; i0 += 4 * REFINE_THREADS) {
+        int sel[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * REFINE_THREADS;
+            sel[u] = i < n_cached ? (mask_row ? mask_row[i] : i) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sel[u] = sel[u] < 0 ? 0 : (mask ? (int)mask[sel[u]] : 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * REFINE_THREADS;
+            if (i < n_cached) {
+                pts_sel[i] = (uint8_t)(sel[u] != 0);
+                pts[0][i] = X[3 * (int64_t)i]; pts[1][i] = X[3 * (int64_t)i + 1]; pts[2][i] = X[3 * (int64_t)i + 2];
+                pts[3][i] = x[2 * (int64_t)i]; pts[4][i] = x[2 * (int64_t)i + 1];
+            }
+        }
+    }
+    __syncthreads();
     int iters_done = 0;
     for (int it = 0; it <= max_iters; ++it) {
         double acc[28];
@@ -681,16 +707,24 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
         double R[9], dR[3][9];
         rotation_and_derivatives(cam, R, dR);
         for (int i = tid; i < n; i += REFINE_THREADS) {
-            if (mask && !mask[mask_row ? mask_row[i] : i]) continue;
-            const double X0 = (double)X[3 * (int64_t)i], X1 = (double)X[3 * (int64_t)i + 1], X2 = (double)X[3 * (int64_t)i + 2];
+            float Xf0, Xf1, Xf2, xf0, xf1;
+            if (i < n_cached) {
+                if (!pts_sel[i]) continue;
+                Xf0 = pts[0][i]; Xf1 = pts[1][i]; Xf2 = pts[2][i]; xf0 = pts[3][i]; xf1 = pts[4][i];
+            } else {
+                if (mask && !mask[mask_row ? mask_row[i] : i]) continue;
+                Xf0 = X[3 * (int64_t)i]; Xf1 = X[3 * (int64_t)i + 1]; Xf2 = X[3 * (int64_t)i + 2];
+                xf0 = x[2 * (int64_t)i]; xf1 = x[2 * (int64_t)i + 1];
+            }
+            const double X0 = (double)Xf0, X1 = (double)Xf1, X2 = (double)Xf2;
             const double Y0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + cam[3], Y1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + cam[4],
                          Y2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + cam[5];
             const double p0 = K.k[0] * Y0 + K.k[1] * Y1 + K.k[2] * Y2, p1 = K.k[3] * Y0 + K.k[4] * Y1 + K.k[5] * Y2,
                          p2 = K.k[6] * Y0 + K.k[7] * Y1 + K.k[8] * Y2;
             const double ip2 = 1.0 / p2;
             double rr[2], Jc[12];
-            rr[0] = p0 * ip2 - (double)x[2 * (int64_t)i];
-            rr[1] = p1 * ip2 - (double)x[2 * (int64_t)i + 1];
+            rr[0] = p0 * ip2 - (double)xf0;
+            rr[1] = p1 * ip2 - (double)xf1;
             const double a2 = -p0 * ip2 * ip2, b2 = -p1 * ip2 * ip2;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {        // d(residual) / d(camera-frame point): also the translation columns
@@ -714,20 +748,24 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
             acc[27] += 0.5 * (rr[0] * rr[0] + rr[1] * rr[1]);
         }
 #pragma unroll
-        for (int k = 0; k < 28; ++k) {
-            const double s = wave_sum_d(acc[k]);
-            if (lane == 63) red[wv][k] = s;
-        }
+        for (int k = 0; k < 28; ++k) part[k][tid] = acc[k];
         __syncthreads();
-        if (tid < 28) {
+        if (tid < 28 * REFINE_RED) {
+            // REFINE_RED lanes per sum: lane j adds entries j, j + REFINE_RED, ..., then exchanges inside the group
+            const int k = tid / REFINE_RED, j = tid % REFINE_RED;
             double s = 0;
-            for (int w = 0; w < REFINE_THREADS / 64; ++w) s += red[w][tid];
-            tot[tid] = s;
+#pragma unroll 8
+            for (int i = j; i < REFINE_THREADS; i += REFINE_RED) s += part[k][i];
+#pragma unroll
+            for (int d = 1; d < REFINE_RED; d *= 2) s += __shfl_xor(s, d);
+            if (j == 0) tot[k] = s;
         }
         __syncthreads();
-        if (tid == 0) {
+        // every lane takes the decision and solves the 6x6 system for itself from the same 28 sums: no broadcast of the
+        // outcome, no further barrier (the next pass writes `part`, and `tot` only after its own first barrier)
+        int stop = 0;
+        {
             const double cost = tot[27];
-            int stop = 0;
             if (!(cost == cost) || fabs(cost) == __builtin_inf() || cost > prev_cost * (1 + 1e-12)) {
                 // diverged: fall back to the pose before the last step
 #pragma unroll
@@ -802,19 +840,14 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                         cmax = fmax(cmax, fabs(cam[k]));
                     }
                     iters_done = it + 1;
-                    // a step nine digits below the pose: converged, and the pass that would only confirm it is saved
-                    if (gmax <= 1e-9 * cmax) stop = 1;
+                    // a step five digits below the pose: converged.  From a RANSAC winner the steps shrink by four to
+                    // five orders of magnitude each (2e-3, 7e-6, 8e-11 of the pose on tracked data), so the pose is then
+                    // good to ~1e-9 and the pass that would only confirm it -- a third of the kernel's time -- is saved
+                    if (gmax <= REFINE_STEP_TOL * cmax) stop = 1;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cam_s[k] = cam[k];
-            stop_s = stop;
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cam[k] = cam_s[k];
-        if (stop_s) break;
-        __syncthreads();
+        if (stop) break;
     }
     if (tid == 0) {
 #pragma unroll
