@@ -128,10 +128,13 @@ __device__ __forceinline__ int refl(int i, int n)
 __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wt, uint32_t &wb)
 {
     const float magic = 12582912.0f;               // 0x4B400000
-    const float ia = 1.f - a, ib = 1.f - b;
-    const uint32_t t00 = __float_as_uint(ia * ib * 16384.f + magic);
-    const uint32_t t01 = __float_as_uint(a * ib * 16384.f + magic);
-    const uint32_t t10 = __float_as_uint(ia * b * 16384.f + magic);
+    // w * 2^14 with the factor split over the two offsets: scaling by a power of two commutes with float rounding,
+    // so (128 - 128 a) is 128 * fl(1 - a) and (128 a') * (128 b') is 2^14 * fl(a' b') bit for bit, three multiplications fewer
+    const float a7 = a * 128.f, b7 = b * 128.f;
+    const float ia = 128.f - a7, ib = 128.f - b7;
+    const uint32_t t00 = __float_as_uint(ia * ib + magic);
+    const uint32_t t01 = __float_as_uint(a7 * ib + magic);
+    const uint32_t t10 = __float_as_uint(ia * b7 + magic);
     const uint32_t iw11 = (16384u + 3u * 0x4B400000u) - (t00 + t01 + t10);
     wt = (t00 & 0xffffu) | (t01 << 16);
     wb = (t10 & 0xffffu) | (iw11 << 16);
@@ -180,6 +183,21 @@ __device__ __forceinline__ uint32_t pack_hi_shr(uint32_t lo, uint32_t src, uint3
         : "+v"(lo)
         : "v"(sh), "v"(src));
     return lo;
+}
+// the same with the shift amount in a scalar register (set once, outside the loops)
+__device__ __forceinline__ uint32_t pack_hi_shr_s(uint32_t lo, uint32_t src, uint32_t sh)
+{
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(lo)
+        : "s"(sh), "v"(src));
+    return lo;
+}
+// a . b: the first term of a sum, so that the accumulator needs no clearing move
+__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
@@ -688,13 +706,13 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
             }
             bilinear_weights(nx - fnx, ny - fny, wt, wb);
 
-            const uint32_t *jt = region + col + (run ? ry * K3_S + rx : 0);
+            // ry, rx <= 4: the 24-bit multiply (a 32-bit product is a quarter-rate 64-bit multiply-add on this target)
+            const uint32_t *jt = region + col + (run ? (int)__umul24((unsigned)ry, (unsigned)K3_S) + rx : 0);
             uint32_t q[22];
 #pragma unroll
             for (int k = 0; k < 22; ++k) q[k] = jt[k * K3_S];
             int b1i = 0, b2i = 0;
-            uint32_t sh9 = 9;
-            asm volatile("" : "+v"(sh9));
+            const uint32_t sh9 = 9;
 #pragma unroll
             for (int p = 0; p < 11; ++p) {
                 // ((S + 256) >> 9) - I == (S + 256 - 512*I) >> 9 with an arithmetic shift; the residuals of two
@@ -703,12 +721,17 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
                 uint32_t d2;
                 if (2 * p + 1 < 21) {
                     const uint32_t s1 = udot2(q[2 * p + 1], wt, udot2(q[2 * p + 2], wb, Ic[2 * p + 1]));
-                    d2 = pack_hi_shr(s0 >> 9, s1, sh9);
+                    d2 = pack_hi_shr_s(s0 >> 9, s1, sh9);
                 } else {
                     d2 = (s0 >> 9) & 0xffffu;
                 }
-                b1i = sdot2(d2, IxP[p], b1i);
-                b2i = sdot2(d2, IyP[p], b2i);
+                if (p == 0) {
+                    b1i = sdot2_first(d2, IxP[p]);
+                    b2i = sdot2_first(d2, IyP[p]);
+                } else {
+                    b1i = sdot2(d2, IxP[p], b1i);
+                    b2i = sdot2(d2, IyP[p], b2i);
+                }
             }
             const float b1 = group_sum21((float)b1i, e_addr, first) * FLT_SCALE;
             const float b2 = group_sum21((float)b2i, e_addr, first) * FLT_SCALE;
