@@ -116,9 +116,10 @@ __device__ __forceinline__ int refl(int i, int n)
 {
     // BORDER_REFLECT_101 for one fold on either side; positions further out are
     // only touched by tile margins that no valid window reads, so they are clamped.
-    i = i < 0 ? -i : i;
-    i = i >= n ? 2 * n - 2 - i : i;
-    return min(max(i, 0), n - 1);
+    // = clamp(i < 0 ? -i : (i >= n ? 2n - 2 - i : i), 0, n - 1): with a = |i| the fold is min(a, 2n - 2 - a), which never
+    // exceeds n - 1, and max(.., 0) supplies the lower clamp (the compiler joins min and max into one median instruction)
+    const int a = max(i, -i);
+    return max(min(a, 2 * n - 2 - a), 0);
 }
 
 // Packed 14-bit bilinear weights {iw00, iw01} and {iw10, iw11} for the fractional
@@ -141,6 +142,9 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wt,
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Lanes for which p holds.  A condition already lives in a scalar mask register; the compiler's own ballot of it
+// is a scalar AND with the execution mask, where __ballot() first turns it into a 0/1 vector and compares that again.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // Pixel pair . weight pair + c.  The product is SIGNED: the fourth weight 2^14 - iw00 - iw01 - iw10 is -1 when
 // all three roundings go up (a fractional offset within ~3e-5 of an integer), and an unsigned 16-bit lane
@@ -201,14 +205,14 @@ __device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
 }
 
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
-// (x0, y0); pixels outside the image follow BORDER_REFLECT_101.  An item is half a
+// (x0, y0) at dword lds_off of the workgroup's LDS array; pixels outside the image follow BORDER_REFLECT_101.  An item is half a
 // (reflected) row: one unaligned 16-byte read yields 15 pairs through v_perm_b32, and
 // the second half starts G1 pixels in so that the two reads end exactly at the last
 // pixel the tile needs (the pairs both halves produce are written twice with the same
 // value).  One item per lane covers the whole tile.  Only items that straddle the
 // left/right image border read their sixteen bytes one by one.
 template <int ROWS, int PAIRS, int STRIDE>
-__device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, int64_t pitch, int w, int h,
+__device__ __forceinline__ void stage_pairs(uint32_t *lds, unsigned lds_off, const uint8_t *img, int64_t pitch, int w, int h,
                                             int x0, int y0, int lane)
 {
     constexpr int G1 = PAIRS + 1 - 16;  // first pixel of the second half
@@ -224,11 +228,14 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
     const unsigned r = (unsigned)idx >> 1;
     const unsigned g = (idx & 1) ? (unsigned)G1 : 0u;
     const unsigned y = (unsigned)refl(y0 + (int)r, h);
-    const uint8_t *row = img + __umul24(y, pitch32);
+    const unsigned rowoff = __umul24(y, pitch32);
+    const uint8_t *row = img + rowoff;
     const int xs = x0 + (int)g;            // first pixel of this item
     uint32_t q[4];
     if (xs >= 0 && xs + 16 <= w) {
-        __builtin_memcpy(q, row + xs, 16);
+        // one unsigned 32-bit offset from the image's (wave-uniform) base: the read then takes the base from scalar
+        // registers and the offset from one vector register, with no 64-bit address arithmetic per lane
+        __builtin_memcpy(q, img + (rowoff + (unsigned)xs), 16);
     } else {
         // the item straddles the left or right image border: sixteen byte reads with
         // BORDER_REFLECT_101, assembled into the same four dwords
@@ -240,7 +247,12 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, const uint8_t *img, i
             q[c] = v;
         }
     }
-    uint32_t *d = lds + (__umul24(r, (unsigned)STRIDE) + g);
+    // the item's LDS position as one register, region offset included: the fifteen stores then differ by small
+    // immediates (left to itself the compiler keeps the region's offset out of the register and spends an add per
+    // pair of stores to bring it back in, because a paired store's immediates reach 1 KB only)
+    unsigned at = lds_off + __umul24(r, (unsigned)STRIDE) + g;
+    asm volatile("" : "+v"(at));
+    uint32_t *d = lds + at;
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
         const int c = j >> 2, o = j & 3;
@@ -273,7 +285,8 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
     if (kp >= A.n) return;
     const int64_t pidx = (int64_t)img * A.n + kp;
 
-    uint32_t *ldsA = lds_all + wid * LDS_WAVE_DWORDS;
+    const unsigned lds_off = wid * LDS_WAVE_DWORDS;
+    uint32_t *ldsA = lds_all + lds_off;
 
     // lane -> window column and 7-row strip; lane 63 shadows lane 0 with zero weight
     const bool active = lane < 63;
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
 
         // ---- template: previous-image tile -> Scharr pairs in registers -> bilinear samples ----
         wave_sync();  // region A may still be read as the coarser level's next-image tile
-        stage_pairs<PT_ROWS, 23, PT_S>(ldsA, pimg, L.ppitch, L.w, L.h, ipx - 1, ipy - 1, lane);
+        stage_pairs<PT_ROWS, 23, PT_S>(lds_all, lds_off, pimg, L.ppitch, L.w, L.h, ipx - 1, ipy - 1, lane);
         wave_sync();
         uint32_t Ic[7];  // 256 - 512*I: accumulator seed that folds rounding and "- I" into the dot product
         v2f Ixy[7];      // template derivatives (Ix, Iy) as float pairs for packed FMAs
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
                 ox = inx - KLT_M; oy = iny - KLT_M;
                 rx = KLT_M; ry = KLT_M;
                 wave_sync();
-                stage_pairs<JT_ROWS, JT_COLS, JT_S>(ldsA, nimg, L.npitch, L.w, L.h, ox, oy, lane);
+                stage_pairs<JT_ROWS, JT_COLS, JT_S>(lds_all, lds_off, nimg, L.npitch, L.w, L.h, ox, oy, lane);
                 wave_sync();
                 have_tile = true;
             }
@@ -603,7 +616,8 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
     // region, scan addresses) is re-derived from the lane counter at the top of each level:
     // holding it across the kernel would cost registers at the 96-VGPR limit of 5 waves/SIMD.
     const int pbase = img * A.n, plast = A.n - 1 - kp_wave;   // wave-uniform
-    uint32_t *lds_wave = lds_all + wid * (K3_KP_WAVE * K3_REGION);
+    const unsigned wave_off = wid * (K3_KP_WAVE * K3_REGION);
+    uint32_t *lds_wave = lds_all + wave_off;
 
     float outx = 0.f, outy = 0.f;
     int status = 1;
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         const int ipx = (int)fpx, ipy = (int)fpy;
         const bool lvl_ok = have && !(ipx < -KLT_WIN || ipx >= L.w || ipy < -KLT_WIN || ipy >= L.h);
         if (have && !lvl_ok && level == 0) { status = 0; errv = 0.f; }
-        const unsigned long long okm = __ballot(lvl_ok);
+        const unsigned long long okm = ballot64(lvl_ok);
         if (okm == 0) continue;
         uint32_t wt, wb;
         bilinear_weights(px - fpx, py - fpy, wt, wb);
@@ -654,14 +668,14 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
             if ((okm >> (21 * gi)) & 1ull) {
                 const int x0 = __builtin_amdgcn_readlane(ipx, 21 * gi) - 1, y0 = __builtin_amdgcn_readlane(ipy, 21 * gi) - 1;
-                stage_pairs<PT_ROWS, 23, K3_S>(lds_wave + gi * K3_REGION, pimg, L.ppitch, L.w, L.h, x0, y0, lane);
+                stage_pairs<PT_ROWS, 23, K3_S>(lds_all, wave_off + gi * K3_REGION, pimg, L.ppitch, L.w, L.h, x0, y0, lane);
             }
         }
         wave_sync();
         uint32_t Ic[21], IxP[11], IyP[11];
         int a11, a12, a22;
         const bool interior = ipx >= 0 && ipx + KLT_WIN < L.w && ipy >= 0 && ipy + KLT_WIN < L.h;
-        if (__ballot(lvl_ok && !interior) == 0)
+        if (ballot64(lvl_ok && !interior) == 0)
             k3_template<false>(region + col, wt, wb, wt, wb, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
         else
             k3_template<true>(region + col, wt, wb, wt, wb, ipx, ipy, col, L.w, L.h, Ic, IxP, IyP, a11, a12, a22);
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         int ox = 0, oy = 0;
         bool have_tile = false;
         for (int j = 0; j < A.max_iters; ++j) {
-            if (__ballot(run) == 0) break;
+            if (ballot64(run) == 0) break;
             const float fnx = floorf(nx), fny = floorf(ny);
             const int inx = (int)fnx, iny = (int)fny;
             if (run && (inx < -KLT_WIN || inx >= L.w || iny < -KLT_WIN || iny >= L.h)) {
@@ -691,14 +705,14 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
             }
             int rx = inx - ox, ry = iny - oy;
             const bool need = run && (!have_tile || rx < 0 || rx > 2 * KLT_M || ry < 0 || ry > 2 * KLT_M);
-            const unsigned long long needm = __ballot(need);
+            const unsigned long long needm = ballot64(need);
             if (needm != 0) {
                 wave_sync();
 #pragma unroll
                 for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
                     if ((needm >> (21 * gi)) & 1ull) {
                         const int sx = __builtin_amdgcn_readlane(inx, 21 * gi) - KLT_M, sy = __builtin_amdgcn_readlane(iny, 21 * gi) - KLT_M;
-                        stage_pairs<JT_ROWS, JT_COLS, K3_S>(lds_wave + gi * K3_REGION, nimg, L.npitch, L.w, L.h, sx, sy, lane);
+                        stage_pairs<JT_ROWS, JT_COLS, K3_S>(lds_all, wave_off + gi * K3_REGION, nimg, L.npitch, L.w, L.h, sx, sy, lane);
                     }
                 }
                 wave_sync();
