@@ -27,6 +27,7 @@
 #define KLT_WIN 21
 #define KLT_HALF 10.0f
 #define KLT_M 2                         // margin of the next-image tile (pixels)
+#define K3_S_ 25                        // tile row stride of the three-keypoint kernel (dwords)
 #define JT_S 35                         // next-image tile row stride (dwords), 7*35 % 32 == 21
 #define JT_ROWS (KLT_WIN + 1 + 2 * KLT_M)
 #define JT_COLS (KLT_WIN + 2 * KLT_M)   // pair columns
@@ -204,6 +205,19 @@ __device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
     return r;
 }
 
+// Fifteen pixel pairs {p[x], p[x+1]} out of sixteen bytes, to consecutive LDS dwords.
+__device__ __forceinline__ void store_pairs(uint32_t *d, const uint32_t (&q)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const int c = j >> 2, o = j & 3;
+        d[j] = o == 0   ? __builtin_amdgcn_perm(0u, q[c], 0x0c010c00u)
+               : o == 1 ? __builtin_amdgcn_perm(0u, q[c], 0x0c020c01u)
+               : o == 2 ? __builtin_amdgcn_perm(0u, q[c], 0x0c030c02u)
+                        : __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c040c03u);
+    }
+}
+
 // Stage a rows x (pairs) tile of 16-bit pixel pairs {p[x], p[x+1]} with origin
 // (x0, y0) at dword lds_off of the workgroup's LDS array; pixels outside the image follow BORDER_REFLECT_101.  An item is half a
 // (reflected) row: one unaligned 16-byte read yields 15 pairs through v_perm_b32, and
@@ -252,15 +266,32 @@ __device__ __forceinline__ void stage_pairs(uint32_t *lds, unsigned lds_off, con
     // pair of stores to bring it back in, because a paired store's immediates reach 1 KB only)
     unsigned at = lds_off + __umul24(r, (unsigned)STRIDE) + g;
     asm volatile("" : "+v"(at));
-    uint32_t *d = lds + at;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) {
-        const int c = j >> 2, o = j & 3;
-        d[j] = o == 0   ? __builtin_amdgcn_perm(0u, q[c], 0x0c010c00u)
-               : o == 1 ? __builtin_amdgcn_perm(0u, q[c], 0x0c020c01u)
-               : o == 2 ? __builtin_amdgcn_perm(0u, q[c], 0x0c030c02u)
-                        : __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c040c03u);
-    }
+    store_pairs(lds + at, q);
+}
+
+// The three-keypoint kernel's staging of a tile that lies inside the image together with the rows and pixels its
+// surplus items touch (26 rows from y0, pixels x0 .. x0 + G1 + 15): no reflection, no per-lane border test.  An
+// item's place in the tile (LDS dword lane_at, byte offset lane_off from the tile's first pixel) depends on the
+// lane only and is formed once per staging site by k3_item(); a tile then costs two adds, one 16-byte read, the
+// fifteen byte shuffles and the stores.  Items 48-51 of a 24-row tile fill rows 24 and 25 of the region, which
+// nothing reads.
+template <int PAIRS>
+__device__ __forceinline__ void k3_item(int lane, unsigned pitch32, unsigned &lane_at, unsigned &lane_off)
+{
+    constexpr int G1 = PAIRS + 1 - 16;
+    int l = lane;
+    asm volatile("" : "+v"(l));             // not hoisted out of the level loop (registers)
+    const unsigned idx = (unsigned)min(l, 2 * (KLT_WIN + 1 + 2 * KLT_M) - 1);
+    const unsigned r = idx >> 1, g = (idx & 1u) ? (unsigned)G1 : 0u;
+    lane_at = __umul24(r, (unsigned)K3_S_) + g;
+    lane_off = __umul24(r, pitch32) + g;
+}
+__device__ __forceinline__ void k3_stage_interior(uint32_t *lds, unsigned at, const uint8_t *img, unsigned off)
+{
+    asm volatile("" : "+v"(at));
+    uint32_t q[4];
+    __builtin_memcpy(q, img + off, 16);
+    store_pairs(lds + at, q);
 }
 
 __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
@@ -479,7 +510,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
 // adjacent samples, matched by pairs of residuals so that v_dot2_i32_i16
 // accumulates b1 and b2 exactly in int32.
 // ---------------------------------------------------------------------------
-#define K3_S 25                        // tile row stride (dwords)
+#define K3_S K3_S_                     // tile row stride (dwords)
 // One keypoint's tile region (dwords).  A dword read serves lanes 0-31 and 32-63 in one LDS cycle each when
 // the 32 lanes of a half hit 32 different banks (bank = dword address mod 32).  A half holds 21 lanes of one
 // keypoint (consecutive columns = consecutive banks) and 10-11 lanes of the middle keypoint: the region
@@ -629,6 +660,7 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
         const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
         const float sc = (float)(1. / (1 << level));
+        const bool roomy = L.w >= JT_ROWS && L.h >= JT_ROWS;    // a tile can lie inside this level at all (its limits below are then >= 0)
         // lane -> keypoint slot g and window column; lane 63 shadows lane 62 (it lies outside every
         // group's scan range, so whatever it computes is never summed).  The barrier keeps these values
         // and the 64-bit addresses below from being hoisted out of the level loop, where they would
@@ -664,11 +696,20 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
 
         // ---- template ----
         wave_sync();  // the regions may still be read as the coarser level's next-image tiles
+        {
+            unsigned lane_at, lane_off;
+            k3_item<23>(lane, (unsigned)L.ppitch, lane_at, lane_off);
 #pragma unroll
-        for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
-            if ((okm >> (21 * gi)) & 1ull) {
-                const int x0 = __builtin_amdgcn_readlane(ipx, 21 * gi) - 1, y0 = __builtin_amdgcn_readlane(ipy, 21 * gi) - 1;
-                stage_pairs<PT_ROWS, 23, K3_S>(lds_all, wave_off + gi * K3_REGION, pimg, L.ppitch, L.w, L.h, x0, y0, lane);
+            for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
+                if ((okm >> (21 * gi)) & 1ull) {
+                    const int x0 = __builtin_amdgcn_readlane(ipx, 21 * gi) - 1, y0 = __builtin_amdgcn_readlane(ipy, 21 * gi) - 1;
+                    // 0 <= x0 <= w - 24 and 0 <= y0 <= h - 26: one unsigned compare each
+                    if (roomy & ((unsigned)x0 <= (unsigned)(L.w - 24)) & ((unsigned)y0 <= (unsigned)(L.h - JT_ROWS)))
+                        k3_stage_interior(lds_all, wave_off + gi * K3_REGION + lane_at, pimg,
+                                          (unsigned)y0 * (unsigned)L.ppitch + (unsigned)x0 + lane_off);
+                    else
+                        stage_pairs<PT_ROWS, 23, K3_S>(lds_all, wave_off + gi * K3_REGION, pimg, L.ppitch, L.w, L.h, x0, y0, lane);
+                }
             }
         }
         wave_sync();
@@ -708,11 +749,17 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
             const unsigned long long needm = ballot64(need);
             if (needm != 0) {
                 wave_sync();
+                unsigned lane_at, lane_off;
+                k3_item<JT_COLS>(lane, (unsigned)L.npitch, lane_at, lane_off);
 #pragma unroll
                 for (int gi = 0; gi < K3_KP_WAVE; ++gi) {
                     if ((needm >> (21 * gi)) & 1ull) {
                         const int sx = __builtin_amdgcn_readlane(inx, 21 * gi) - KLT_M, sy = __builtin_amdgcn_readlane(iny, 21 * gi) - KLT_M;
-                        stage_pairs<JT_ROWS, JT_COLS, K3_S>(lds_all, wave_off + gi * K3_REGION, nimg, L.npitch, L.w, L.h, sx, sy, lane);
+                        if (roomy & ((unsigned)sx <= (unsigned)(L.w - JT_ROWS)) & ((unsigned)sy <= (unsigned)(L.h - JT_ROWS)))
+                            k3_stage_interior(lds_all, wave_off + gi * K3_REGION + lane_at, nimg,
+                                              (unsigned)sy * (unsigned)L.npitch + (unsigned)sx + lane_off);
+                        else
+                            stage_pairs<JT_ROWS, JT_COLS, K3_S>(lds_all, wave_off + gi * K3_REGION, nimg, L.npitch, L.w, L.h, sx, sy, lane);
                     }
                 }
                 wave_sync();
