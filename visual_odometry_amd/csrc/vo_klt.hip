@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES, 8) void klt_track_kernel(KltArgs A)
         const KltLevel L = A.lv[level];
         const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
         const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
-        const float sc = (float)(1. / (1 << level));
+        const float sc = __uint_as_float((unsigned)(127 - level) << 23);   // 2^-level, built from its exponent (a float64 division otherwise)
         float px = px0 * sc, py = py0 * sc;
         float nx, ny;
         if (level == A.max_level) {
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64 * K3_WAVES, 5) void klt_track3_kernel(KltArgs A)
         const KltLevel L = A.lv[level];
         const uint8_t *pimg = L.prev + (int64_t)img * L.pstride;
         const uint8_t *nimg = L.next + (int64_t)img * L.nstride;
-        const float sc = (float)(1. / (1 << level));
+        const float sc = __uint_as_float((unsigned)(127 - level) << 23);   // 2^-level, built from its exponent (a float64 division otherwise)
         const bool roomy = L.w >= JT_ROWS && L.h >= JT_ROWS;    // a tile can lie inside this level at all (its limits below are then >= 0)
         // lane -> keypoint slot g and window column; lane 63 shadows lane 62 (it lies outside every
         // group's scan range, so whatever it computes is never summed).  The barrier keeps these values
