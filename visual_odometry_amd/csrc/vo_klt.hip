@@ -138,8 +138,9 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wt,
     const uint32_t t01 = __float_as_uint(a7 * ib + magic);
     const uint32_t t10 = __float_as_uint(ia * b7 + magic);
     const uint32_t iw11 = (16384u + 3u * 0x4B400000u) - (t00 + t01 + t10);
-    wt = (t00 & 0xffffu) | (t01 << 16);
-    wb = (t10 & 0xffffu) | (iw11 << 16);
+    // low halves side by side: one byte shuffle each instead of a mask, a shift and an or
+    wt = __builtin_amdgcn_perm(t01, t00, 0x05040100u);
+    wb = __builtin_amdgcn_perm(iw11, t10, 0x05040100u);
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
