@@ -256,6 +256,18 @@ int vo_cheirality_vote(vo_ctx *ctx, const float *pts1, const float *pts2, int n,
 typedef struct vo_ba vo_ba;
 int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const double *obs,
                  const double *K, int obs_start, int mem, vo_ba **out);
+/* vo_ba_create_filtered: vo_ba_create preceded by the outlier pre-filter of BundleAdjustment._preprocess_data
+ * (vo_pipeline/bundleAdjustment.py:111-134) on the device: obs is (O,2) float64, or float32 when obs_f32 is set (the
+ * pipeline's keypoints, widened on the device exactly as the host conversion would); the residual is evaluated at x0
+ * (6F + 3P float64, follows `mem`), observations whose squared reprojection error exceeds max_sq_error are dropped (BA_DISTANCE_TH,
+ * params.py:44; the reference's test is "difference > threshold"), the kept ones are compacted in order into the
+ * solver, and the observations of cameras below n_frozen_cams (int(F/4)+1, bundleAdjustment.py:54-65; counted, the
+ * observations being sorted by camera) get no Jacobian rows.  One upload of the observations, one synchronisation.
+ * n_kept / obs_start (host): observations kept, and how many of them lead without Jacobian rows.  The solver equals
+ * the one vo_ba_create builds from the kept observations. */
+int vo_ba_create_filtered(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const void *obs,
+                          int obs_f32, const double *K, const double *x0, double max_sq_error, int n_frozen_cams, int mem,
+                          vo_ba **out, int32_t *n_kept, int32_t *obs_start);
 void vo_ba_destroy(vo_ba *ba);
 int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost);
 int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved);

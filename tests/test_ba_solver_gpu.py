@@ -132,3 +132,84 @@ def test_empty_window_state_errors_and_bad_indices(ctx):
         hip.BaSolver(ctx, 2, 3, np.array([0, 2]), np.array([0, 1]), np.zeros((2, 2)), K, 0)   # camera 2 of 2
     with pytest.raises(ValueError):
         hip.BaSolver(ctx, 2, 3, np.array([0, 1]), np.array([0, 1, 2]), np.zeros((2, 2)), K, 0)
+
+
+@pytest.mark.parametrize("F,P,vis,n_bad", [(6, 150, 0.7, 25), (30, 500, 0.4, 200), (12, 200, 0.6, 0), (1, 40, 1.0, 3)])
+def test_filtered_solver_equals_host_prefilter(ctx, F, P, vis, n_bad):
+    """vo_ba_create_filtered (residual at x0, outlier filter, compaction, landmark lists on the device) against the
+    same steps on the host followed by vo_ba_create: kept count and frozen count exactly, cost and one trial step to
+    the last bits."""
+    from visual_odometry_amd import hip, params
+    from visual_odometry_amd.vo_pipeline.bundleAdjustment import BundleAdjustment
+    pb = synth.ba_problem(F=F, P=P, visibility=vis, seed=100 + F, obs_noise=0.4)
+    ci, pi, K = pb["ci"], pb["pi"], pb["K"]
+    obs = pb["obs"].astype(np.float64).copy()
+    rng = np.random.default_rng(F)
+    bad = rng.choice(ci.size, size=min(n_bad, ci.size), replace=False)
+    obs[bad] += rng.uniform(15, 60, (bad.size, 2)) * rng.choice([-1, 1], (bad.size, 2))     # beyond sqrt(BA_DISTANCE_TH) = 10 px
+    x0 = pb["x"] + rng.normal(0, 1e-3, pb["x"].size)
+    n_frozen = int(F / 4) + 1
+    # host route
+    r, _ = hip.ba_residual(ctx, x0, F, P, ci, pi, obs, K)
+    d = r[0::2] ** 2 + r[1::2] ** 2
+    keep = ~(d > params.BA_DISTANCE_TH)
+    assert keep.sum() == ci.size - bad.size or n_bad == 0 or keep.sum() < ci.size
+    ci2, pi2, obs2 = ci[keep], pi[keep], obs[keep]
+    start = int(np.count_nonzero(ci2 < n_frozen))
+    a = hip.BaSolver(ctx, F, P, ci2, pi2, obs2, K, start)
+    b = hip.BaSolver.filtered(ctx, F, P, ci, pi, obs, K, x0, params.BA_DISTANCE_TH, n_frozen)
+    try:
+        assert b.O == ci2.size and b.obs_start == start
+        # float64 sums that pass through atomics (cost, camera blocks) differ in the last bits from run to run
+        ca, cb = a.linearize(x0), b.linearize(x0)
+        assert ca == pytest.approx(cb, rel=1e-12)
+        if start < ci2.size:
+            (na, sa), (nb, sb) = a.try_step(1e-3), b.try_step(1e-3)
+            assert sa == sb and na == pytest.approx(nb, rel=1e-11)
+            np.testing.assert_allclose(a.params(candidate=True), b.params(candidate=True), rtol=0, atol=1e-9)
+    finally:
+        a.close(); b.close()
+    # float32 observations (the pipeline's keypoints) are widened on the device: same solver as widening on the host
+    o32 = obs.astype(np.float32)
+    a = hip.BaSolver.filtered(ctx, F, P, ci, pi, o32.astype(np.float64), K, x0, params.BA_DISTANCE_TH, n_frozen)
+    b = hip.BaSolver.filtered(ctx, F, P, ci, pi, o32, K, x0, params.BA_DISTANCE_TH, n_frozen)
+    try:
+        assert (a.O, a.obs_start) == (b.O, b.obs_start)
+        assert a.linearize(x0) == pytest.approx(b.linearize(x0), rel=1e-12)
+    finally:
+        a.close(); b.close()
+    # the drop-in class takes the device route
+    if F >= 4:
+        from scipy.spatial.transform import Rotation
+        M = np.zeros((F, 3, 4))
+        cams = x0[:6 * F].reshape(F, 6)
+        M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
+        M[:, :, 3] = cams[:, 3:]
+        adj_M, adj_L = BundleAdjustment(K).bundle_adjustment(M, x0[6 * F:].reshape(P, 3), ci, pi, obs)
+        assert np.isfinite(adj_M).all() and np.isfinite(adj_L).all()
+        np.testing.assert_allclose(adj_M[:n_frozen], M[:n_frozen], atol=1e-9)      # frozen cameras stay
+
+
+def test_filtered_solver_edge_cases(ctx):
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=5, P=60, visibility=0.8, seed=3, obs_noise=0.3)
+    ci, pi, K, x0 = pb["ci"], pb["pi"], pb["K"], pb["x"]
+    obs = pb["obs"].astype(np.float64)
+    far = obs + 500.0                                                   # every observation is an outlier
+    s = hip.BaSolver.filtered(ctx, 5, 60, ci, pi, far, K, x0, 100.0, 2)
+    assert s.O == 0 and s.obs_start == 0
+    s.close()
+    s = hip.BaSolver.filtered(ctx, 5, 60, ci[:0], pi[:0], obs[:0], K, x0, 100.0, 2)      # no observations at all
+    assert s.O == 0
+    s.close()
+    r, _ = hip.ba_residual(ctx, x0, 5, 60, ci, pi, obs, K)
+    kept = int(np.count_nonzero(~(r[0::2] ** 2 + r[1::2] ** 2 > 100.0)))
+    s = hip.BaSolver.filtered(ctx, 5, 60, ci, pi, obs, K, x0, 100.0, 9)                  # every camera frozen
+    assert s.O == kept and s.obs_start == kept
+    assert s.linearize(x0) > 0
+    s.close()
+    bad = pi.copy(); bad[7] = 60
+    with pytest.raises(ValueError):
+        hip.BaSolver.filtered(ctx, 5, 60, ci, bad, obs, K, x0, 100.0, 2)
+    with pytest.raises(ValueError):
+        hip.BaSolver.filtered(ctx, 5, 60, ci, pi[:-1], obs, K, x0, 100.0, 2)

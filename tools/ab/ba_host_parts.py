@@ -41,5 +41,7 @@ for M, lm, ci, pi, kp in calls[-3:]:
         s = hip.BaSolver(vo.bundle_adjustment and __import__("visual_odometry_amd.vo_pipeline._runtime", fromlist=["x"]).context(), F, P, ci2, pi2, obs, ba.K, start)
         s.close()
     res["solver_create_close"], _ = med(mk)
-    res["lm"], _ = med(lambda: ba._levenberg_marquardt(x0.copy(), F, P, ci2, pi2, obs, start, 50, 1e-4), 7)
+    ctxr = __import__("visual_odometry_amd.vo_pipeline._runtime", fromlist=["x"]).context()
+    res["lm"], _ = med(lambda: ba._levenberg_marquardt(x0.copy(), hip.BaSolver(ctxr, F, P, ci2, pi2, obs, ba.K, start), 50, 1e-4), 7)
+    res["filtered_create_close"], _ = med(lambda: hip.BaSolver.filtered(ctxr, F, P, ci, pi, kp, ba.K, x0, params.BA_DISTANCE_TH, int(F / 4) + 1).close())
     print(json.dumps(res))

@@ -70,6 +70,9 @@ SIGNATURES = {
                                           ctypes.c_int, c_vp, c_vp, ctypes.c_int]),
     "vo_ba_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_f64p, ctypes.c_int,
                                     ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "vo_ba_create_filtered": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_vp,
+                                             ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp),
+                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "vo_ba_destroy": (None, [c_vp]),
     "vo_ba_linearize": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p]),
     "vo_ba_try_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_f64p, ctypes.POINTER(ctypes.c_int)]),

@@ -951,6 +951,7 @@ struct vo_ba {
     int F = 0, P = 0, O = 0, n = 0, obs_start = 0;
     BaK K;
     char *pool = nullptr;
+    size_t pool_bytes = 0;
     int64_t *ci = nullptr, *pi = nullptr;
     int *cam32 = nullptr, *pptr = nullptr, *pobs = nullptr, *flag = nullptr;
     double *obs = nullptr, *r = nullptr, *Jp = nullptr, *cam_rep = nullptr, *Dpinv = nullptr, *S = nullptr, *rhs = nullptr, *dc = nullptr;
@@ -1789,13 +1790,136 @@ static int ba_linearize_into(vo_ba *ba, int slot)
     return VO_OK;
 }
 
+// The solver's device pool for F cameras, P landmarks and room for O observations.  One pool is kept by the context
+// between solver objects (a window's solver is built and destroyed at every keyframe; hipMalloc + hipFree of tens of MB
+// were a quarter of building one).
+static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **out)
+{
+    vo_ba *ba = new vo_ba();
+    ba->ctx = ctx; ba->F = F; ba->P = P; ba->O = O; ba->n = 6 * F;
+    memcpy(ba->K.k, K, sizeof(ba->K.k));
+    const size_t n = (size_t)ba->n, np_ = n + 3 * (size_t)P, Oz = (size_t)(O ? O : 1);
+    size_t tot = 0;
+    auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
+    const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
+                 o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
+                 o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
+                 o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8);
+    size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
+    for (int s = 0; s < 2; ++s) {
+        o_x[s] = take(np_ * 8); o_cost[s] = take(8); o_Hcc[s] = take((size_t)F * 288); o_Hpp[s] = take((size_t)P * 72);
+        o_Hcp[s] = take(Oz * 144); o_g[s] = take(np_ * 8);
+    }
+    if (ctx->ba_pool && ctx->ba_pool_bytes >= tot) {
+        ba->pool = ctx->ba_pool;
+        ba->pool_bytes = ctx->ba_pool_bytes;
+        ctx->ba_pool = nullptr;
+        ctx->ba_pool_bytes = 0;
+    } else {
+        if (ctx->ba_pool) {
+            // too small for this window (windows grow as the run goes on): let it go, so that this solver's pool is
+            // the one kept when it is destroyed
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->ba_pool);
+            ctx->ba_pool = nullptr;
+            ctx->ba_pool_bytes = 0;
+        }
+        const size_t room = tot + tot / 4;       // windows of the next keyframes fit without another allocation
+        hipError_t e = hipMalloc((void **)&ba->pool, room);
+        if (e != hipSuccess) {
+            e = hipMalloc((void **)&ba->pool, tot);
+            if (e != hipSuccess) {
+                vo_set_error("vo_ba_create: hipMalloc(%zu) failed: %s", tot, hipGetErrorString(e));
+                delete ba;
+                return VO_ENOMEM;
+            }
+            ba->pool_bytes = tot;
+        } else {
+            ba->pool_bytes = room;
+        }
+    }
+    char *b = ba->pool;
+    ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
+    ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
+    ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
+    ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
+    ba->Lf = (double *)(b + o_Lf); ba->zf = (double *)(b + o_zf); ba->dinv = (double *)(b + o_dinv);
+    for (int s = 0; s < 2; ++s) {
+        ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
+        ba->Hpp[s] = (double *)(b + o_Hpp[s]); ba->Hcp[s] = (double *)(b + o_Hcp[s]); ba->g[s] = (double *)(b + o_g[s]);
+    }
+    *out = ba;
+    return VO_OK;
+}
+
+static void ba_release_pool(vo_ba *ba)
+{
+    if (!ba->pool) return;
+    vo_ctx *ctx = ba->ctx;
+    if (!ctx->ba_pool) { ctx->ba_pool = ba->pool; ctx->ba_pool_bytes = ba->pool_bytes; }
+    else (void)hipFree(ba->pool);
+    ba->pool = nullptr;
+}
+
+// Where the reduced system lives and which kernels solve it: decided once per solver from its size and from the
+// first camera with unknowns.
+static void ba_configure(vo_ba *ba)
+{
+    const size_t n = (size_t)ba->n;
+    const int F = ba->F, cam_first = ba->cam_first;
+    // keep the reduced system in LDS when it fits (up to the 160 KB of a gfx950 CU)
+    const size_t need = (n * n + 2 * n) * 8;
+    ba->lds_bytes = 0;
+    if (need <= 60 * 1024) ba->lds_bytes = need;
+    else if (need + 1024 <= 160 * 1024 &&
+             hipFuncSetAttribute((const void *)ba_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess &&
+             hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
+        ba->lds_bytes = need;
+    (void)hipGetLastError();
+    if (!ba->lds_bytes) {
+        // panel (W columns of n + 1 rows), the pivots' reciprocals and the right-hand side in LDS
+        const long budget = 150 * 1024 - 16 * (long)n;
+        long w = budget / (8 * ((long)n + 1));
+        if (w > SOLVEB_MAX_W) w = SOLVEB_MAX_W;
+        const size_t lds = ((size_t)w * (n + 1) + 2 * (size_t)n) * 8;
+        if (w >= 4 && hipFuncSetAttribute((const void *)ba_solve_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds) == hipSuccess &&
+            hipFuncSetAttribute((const void *)ba_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+                hipSuccess) {
+            ba->solve_w = (int)w;
+            ba->solve_lds = lds;
+        }
+        (void)hipGetLastError();
+        // strips of the Schur complement: as many cameras' rows as fit in LDS beside nothing else
+        // strips of the Schur complement: LDS for one camera's rows over the whole live width at least
+        const size_t live = n - 6 * (size_t)cam_first;
+        size_t sbudget = 150 * 1024 / 8;
+        if (sbudget < 6 * live) sbudget = 0;
+        int strips = 0, sc0, sc1;
+        while (sbudget && ba_strip_bounds(cam_first, F, (int)sbudget, strips, sc0, sc1)) ++strips;
+        if (strips >= 1 && hipFuncSetAttribute((const void *)ba_schur_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(sbudget * 8)) == hipSuccess) {
+            ba->n_strips = strips;
+            ba->strip_budget = (int)sbudget;
+            ba->strip_lds = sbudget * 8;
+        }
+        (void)hipGetLastError();
+        ba->panels = ba->solve_w > 0;
+        const char *env = getenv("VO_BA_SOLVE");          // earlier kernels (comparison runs, tests): "columns", or
+        if (env && env[0] == 'c') { ba->solve_w = 0; ba->n_strips = 0; ba->panels = false; }
+        if (env && env[0] == 'b') ba->panels = false;     // "blocked": the blocked factorisation in one workgroup
+        const char *env2 = getenv("VO_BA_SCHUR");         // "global": sums straight into global memory
+        if (env2 && env2[0] == 'g') ba->n_strips = 0;
+    }
+}
+
 extern "C" void vo_ba_destroy(vo_ba *ba)
 {
     if (!ba) return;
     if (ba->pool && vo_ctx_is_live(ba->ctx)) {
         (void)hipSetDevice(ba->ctx->device);
         (void)hipStreamSynchronize(ba->ctx->stream);
-        (void)hipFree(ba->pool);
+        ba_release_pool(ba);
     }
     delete ba;
 }
@@ -1854,103 +1978,239 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             free(fill);
         }
     }
+    if (rc == VO_OK) rc = ba_alloc(ctx, F, P, O, K, &ba);
     if (rc == VO_OK) {
-        ba = new vo_ba();
-        ba->ctx = ctx; ba->F = F; ba->P = P; ba->O = O; ba->n = 6 * F; ba->obs_start = obs_start; ba->cam_first = cam_first;
-        memcpy(ba->K.k, K, sizeof(ba->K.k));
-        const size_t n = (size_t)ba->n, np_ = n + 3 * (size_t)P, Oz = (size_t)(O ? O : 1);
-        // pool layout
-        size_t tot = 0;
-        auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
-        const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
-                     o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
-                     o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
-                     o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8);
-        size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
-        for (int s = 0; s < 2; ++s) {
-            o_x[s] = take(np_ * 8); o_cost[s] = take(8); o_Hcc[s] = take((size_t)F * 288); o_Hpp[s] = take((size_t)P * 72);
-            o_Hcp[s] = take(Oz * 144); o_g[s] = take(np_ * 8);
+        ba->obs_start = obs_start; ba->cam_first = cam_first;
+        const hipMemcpyKind kind = mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        hipError_t e = hipSuccess;
+        if (O) {
+            e = hipMemcpy(ba->ci, sci, (size_t)O * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(ba->pi, spi, (size_t)O * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(ba->cam32, cam32, (size_t)O * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(ba->pobs, pobs, (size_t)O * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(ba->obs, obs, (size_t)O * 16, kind);
         }
-        hipError_t e = hipMalloc((void **)&ba->pool, tot);
+        if (e == hipSuccess) e = hipMemcpy(ba->pptr, pptr, ((size_t)P + 1) * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            vo_set_error("vo_ba_create: hipMalloc(%zu) failed: %s", tot, hipGetErrorString(e));
-            delete ba; ba = nullptr; rc = VO_ENOMEM;
-        } else {
-            char *b = ba->pool;
-            ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
-            ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
-            ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
-            ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
-            ba->Lf = (double *)(b + o_Lf); ba->zf = (double *)(b + o_zf); ba->dinv = (double *)(b + o_dinv);
-            for (int s = 0; s < 2; ++s) {
-                ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
-                ba->Hpp[s] = (double *)(b + o_Hpp[s]); ba->Hcp[s] = (double *)(b + o_Hcp[s]); ba->g[s] = (double *)(b + o_g[s]);
-            }
-            const hipMemcpyKind kind = mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-            e = hipSuccess;
-            if (O) {
-                e = hipMemcpy(ba->ci, sci, (size_t)O * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(ba->pi, spi, (size_t)O * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(ba->cam32, cam32, (size_t)O * 4, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(ba->pobs, pobs, (size_t)O * 4, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(ba->obs, obs, (size_t)O * 16, kind);
-            }
-            if (e == hipSuccess) e = hipMemcpy(ba->pptr, pptr, ((size_t)P + 1) * 4, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                vo_set_error("vo_ba_create: upload failed: %s", hipGetErrorString(e));
-                (void)hipFree(ba->pool); delete ba; ba = nullptr; rc = VO_EHIP;
-            }
-        }
-        if (ba) {
-            // keep the reduced system in LDS when it fits (up to the 160 KB of a gfx950 CU)
-            const size_t need = (n * n + 2 * n) * 8;
-            ba->lds_bytes = 0;
-            if (need <= 60 * 1024) ba->lds_bytes = need;
-            else if (need + 1024 <= 160 * 1024 &&
-                     hipFuncSetAttribute((const void *)ba_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess &&
-                     hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
-                ba->lds_bytes = need;
-            (void)hipGetLastError();
-            if (!ba->lds_bytes) {
-                // panel (W columns of n + 1 rows), the pivots' reciprocals and the right-hand side in LDS
-                const long budget = 150 * 1024 - 16 * (long)n;
-                long w = budget / (8 * ((long)n + 1));
-                if (w > SOLVEB_MAX_W) w = SOLVEB_MAX_W;
-                const size_t lds = ((size_t)w * (n + 1) + 2 * (size_t)n) * 8;
-                if (w >= 4 && hipFuncSetAttribute((const void *)ba_solve_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)lds) == hipSuccess &&
-                    hipFuncSetAttribute((const void *)ba_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
-                        hipSuccess) {
-                    ba->solve_w = (int)w;
-                    ba->solve_lds = lds;
-                }
-                (void)hipGetLastError();
-                // strips of the Schur complement: as many cameras' rows as fit in LDS beside nothing else
-                // strips of the Schur complement: LDS for one camera's rows over the whole live width at least
-                const size_t live = n - 6 * (size_t)cam_first;
-                size_t sbudget = 150 * 1024 / 8;
-                if (sbudget < 6 * live) sbudget = 0;
-                int strips = 0, sc0, sc1;
-                while (sbudget && ba_strip_bounds(cam_first, F, (int)sbudget, strips, sc0, sc1)) ++strips;
-                if (strips >= 1 && hipFuncSetAttribute((const void *)ba_schur_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)(sbudget * 8)) == hipSuccess) {
-                    ba->n_strips = strips;
-                    ba->strip_budget = (int)sbudget;
-                    ba->strip_lds = sbudget * 8;
-                }
-                (void)hipGetLastError();
-                ba->panels = ba->solve_w > 0;
-                const char *env = getenv("VO_BA_SOLVE");          // earlier kernels (comparison runs, tests): "columns", or
-                if (env && env[0] == 'c') { ba->solve_w = 0; ba->n_strips = 0; ba->panels = false; }
-                if (env && env[0] == 'b') ba->panels = false;     // "blocked": the blocked factorisation in one workgroup
-                const char *env2 = getenv("VO_BA_SCHUR");         // "global": sums straight into global memory
-                if (env2 && env2[0] == 'g') ba->n_strips = 0;
-            }
+            vo_set_error("vo_ba_create: upload failed: %s", hipGetErrorString(e));
+            ba_release_pool(ba); delete ba; ba = nullptr; rc = VO_EHIP;
         }
     }
+    if (ba) ba_configure(ba);
     free(hci); free(hpi); free(cam32); free(pptr); free(pobs);
     *out = ba;
     return rc;
+}
+
+// ---- a window's solver built from raw observations: outlier pre-filter, compaction and lists on the device ----
+// BundleAdjustment._preprocess_data (vo_pipeline/bundleAdjustment.py:111-134) evaluates the residual at the start,
+// drops the observations whose squared reprojection error exceeds a threshold, and hands the rest to the solver.  Done
+// on the host that is three passes over PCIe (observations up, residuals down, kept observations up again) and a
+// fancy-indexing copy per array.  Here the observations go up once: residual at x0 (the solver's own kernel), keep
+// flags, an exclusive scan, a stable compaction straight into the solver's arrays, and the landmark-major lists of
+// the kept observations with Jacobian rows (count per landmark, scan, fill, each list sorted by observation index
+// so that the sums that walk them are the same in every run and equal to those of host-built lists).
+struct BaMeta { int kept, frozen, cam_first, bad; };
+
+__global__ __launch_bounds__(256) void ba_keep_kernel(const double *__restrict__ r, const int64_t *__restrict__ ci,
+                                                      const int64_t *__restrict__ pi, int O, int F, int P, double max_sq,
+                                                      int *__restrict__ keep, BaMeta *__restrict__ meta)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { meta->frozen = 0; meta->cam_first = F; }
+    if (i >= O) return;
+    const int64_t c = ci[i], p = pi[i];
+    if (c < 0 || c >= F || p < 0 || p >= P) {
+        meta->bad = i + 1;                 // any offender will do for the message
+        keep[i] = 0;
+        return;
+    }
+    const double u = r[2 * (int64_t)i], v = r[2 * (int64_t)i + 1];
+    keep[i] = (u * u + v * v > max_sq) ? 0 : 1;     // the reference drops on "difference > threshold": NaN stays
+}
+
+__global__ __launch_bounds__(256) void ba_compact_kernel(const int *__restrict__ keep, const int *__restrict__ pos,
+                                                         const int64_t *__restrict__ ci, const int64_t *__restrict__ pi,
+                                                         const double *__restrict__ obs, int O, int n_frozen,
+                                                         int64_t *__restrict__ ci2, int64_t *__restrict__ pi2,
+                                                         int *__restrict__ cam32, double *__restrict__ obs2,
+                                                         BaMeta *__restrict__ meta)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool frozen = false;
+    if (i < O && keep[i]) {
+        const int j = pos[i];
+        const int64_t c = ci[i];
+        ci2[j] = c; pi2[j] = pi[i]; cam32[j] = (int)c;
+        *(double2 *)(obs2 + 2 * (int64_t)j) = *(const double2 *)(obs + 2 * (int64_t)i);
+        frozen = c < n_frozen;
+    }
+    const unsigned long long b = __ballot(frozen);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&meta->frozen, __popcll(b));
+    if (i == 0) meta->kept = pos[O];
+}
+
+// observations kept .. with Jacobian rows: position >= meta->frozen (the caller's observations are sorted by camera)
+__global__ __launch_bounds__(256) void ba_lists_count_kernel(const int64_t *__restrict__ pi2, const int *__restrict__ cam32,
+                                                             BaMeta *__restrict__ meta, int *__restrict__ cnt,
+                                                             int *__restrict__ slot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < meta->kept && i >= meta->frozen;
+    int cam = 0x7fffffff;
+    if (live) {
+        slot[i] = atomicAdd(cnt + pi2[i], 1);
+        cam = cam32[i];
+    }
+    // the smallest camera with unknowns: one atomic per wavefront (one per observation would queue on a single address)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cam = min(cam, __shfl_xor(cam, d));
+    if ((threadIdx.x & 63) == 0 && cam != 0x7fffffff) atomicMin(&meta->cam_first, cam);
+}
+
+__global__ __launch_bounds__(256) void ba_lists_fill_kernel(const int64_t *__restrict__ pi2, const BaMeta *__restrict__ meta,
+                                                            const int *__restrict__ pptr, const int *__restrict__ slot,
+                                                            int *__restrict__ pobs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= meta->kept || i < meta->frozen) return;
+    pobs[pptr[pi2[i]] + slot[i]] = i;
+}
+
+// Ascending observation index within every landmark's list.  A wavefront takes a list: lane l holds entry l, counts
+// the entries below its own (the indices are distinct, so that count is its place) and stores it there.  Lists
+// longer than a wavefront (more than 64 cameras see the landmark) are sorted by one lane.
+__global__ __launch_bounds__(256) void ba_lists_sort_kernel(int P, const int *__restrict__ pptr, int *__restrict__ pobs)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int o0 = pptr[p], k = pptr[p + 1] - o0;
+    if (k <= 1) return;
+    if (k <= 64) {
+        const int v = lane < k ? pobs[o0 + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += __shfl(v, j) < v ? 1 : 0;
+        if (lane < k) pobs[o0 + rank] = v;        // every lane has read its entry before any lane writes (one wavefront)
+        return;
+    }
+    if (lane == 0)
+        for (int a = 1; a < k; ++a) {
+            const int v = pobs[o0 + a];
+            int b = a - 1;
+            while (b >= 0 && pobs[o0 + b] > v) { pobs[o0 + b + 1] = pobs[o0 + b]; --b; }
+            pobs[o0 + b + 1] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void ba_widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+
+extern "C" int vo_ba_create_filtered(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const void *obs_in,
+                                     int obs_f32, const double *K, const double *x0, double max_sq_error, int n_frozen_cams,
+                                     int mem, vo_ba **out, int32_t *n_kept, int32_t *obs_start)
+{
+    const double *obs = (const double *)obs_in;
+    VO_REQUIRE(ctx && out && K && x0 && n_kept && obs_start, "vo_ba_create_filtered: NULL argument");
+    *out = nullptr;
+    VO_REQUIRE(F >= 1 && P >= 1 && O >= 0, "vo_ba_create_filtered: F=%d P=%d O=%d", F, P, O);
+    VO_REQUIRE(F <= 256, "vo_ba_create_filtered: at most 256 cameras per window (F=%d)", F);
+    VO_REQUIRE(n_frozen_cams >= 0, "vo_ba_create_filtered: n_frozen_cams=%d", n_frozen_cams);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_create_filtered: bad mem flag %d", mem);
+    VO_REQUIRE(O == 0 || (ci && pi && obs), "vo_ba_create_filtered: NULL observation buffers");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    vo_ba *ba = nullptr;
+    int rc = ba_alloc(ctx, F, P, O, K, &ba);
+    if (rc) return rc;
+    auto fail = [&](int code) { ba_release_pool(ba); delete ba; return code; };
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)P;
+    // inputs on the device: the caller's arrays, or a staging block (observations | camera indices | landmark indices)
+    const int64_t *d_ci = ci, *d_pi = pi;
+    const double *d_obs = obs;
+    const int nblk_o = (O + BA_SCAN - 1) / BA_SCAN, nblk_p = (P + BA_SCAN - 1) / BA_SCAN;
+    void *wp;
+    {
+        const size_t in_bytes = mem == VO_MEM_HOST ? ((size_t)O * 40 + 1024) : (obs_f32 ? (size_t)O * 16 + 256 : 0);
+        const size_t work = ((size_t)(nblk_o > nblk_p ? nblk_o : nblk_p) + 1) * 4 + 256 + sizeof(BaMeta) + 256 + 3 * ((size_t)O + 64) * 4;
+        if ((rc = vo_stage_reserve(ctx, 0, in_bytes + work, &wp))) return fail(rc);
+    }
+    char *wb = (char *)wp;
+    int *d_bsum = (int *)wb;
+    BaMeta *d_meta = (BaMeta *)(wb + (((size_t)(nblk_o > nblk_p ? nblk_o : nblk_p) + 1) * 4 + 255) / 256 * 256);
+    // keep flags | positions (O + 1) | list slots
+    int *d_keep = (int *)((char *)d_meta + 256), *d_pos = d_keep + ((size_t)O + 64), *d_slot = d_pos + ((size_t)O + 64);
+    char *in_base = (char *)(d_slot + ((size_t)O + 64));
+    if (O && (mem == VO_MEM_HOST || obs_f32)) {
+        // float32 observations (what the pipeline holds) travel as they are and are widened on the device
+        double *t_obs = (double *)in_base;
+        const float *d_f32 = (const float *)obs_in;
+        if (mem == VO_MEM_HOST) {
+            int64_t *t_ci = (int64_t *)(in_base + ((size_t)O * 16 + 255) / 256 * 256);
+            int64_t *t_pi = (int64_t *)((char *)t_ci + ((size_t)O * 8 + 255) / 256 * 256);
+            float *t_f32 = (float *)((char *)t_pi + ((size_t)O * 8 + 255) / 256 * 256);
+            if (obs_f32) { if ((rc = vo_upload(ctx, t_f32, obs_in, (size_t)O * 8))) return fail(rc); d_f32 = t_f32; }
+            else if ((rc = vo_upload(ctx, t_obs, obs_in, (size_t)O * 16))) return fail(rc);
+            if ((rc = vo_upload(ctx, t_ci, ci, (size_t)O * 8)) || (rc = vo_upload(ctx, t_pi, pi, (size_t)O * 8))) return fail(rc);
+            d_ci = t_ci; d_pi = t_pi;
+        }
+        if (obs_f32)
+            hipLaunchKernelGGL(ba_widen_kernel, dim3((unsigned)(((size_t)O * 2 + 255) / 256)), dim3(256), 0, ctx->stream, d_f32, t_obs,
+                               (size_t)O * 2);
+        d_obs = t_obs;
+    }
+    if (mem == VO_MEM_HOST) { if ((rc = vo_upload(ctx, ba->x[0], x0, np_ * 8))) return fail(rc); }
+    else if (hipMemcpyAsync(ba->x[0], x0, np_ * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        vo_set_error("vo_ba_create_filtered: copy of x0 failed");
+        return fail(VO_EHIP);
+    }
+    // per-landmark counts in the pool's damped-inverse block (free until the first trial step)
+    int *d_cnt = (int *)ba->Dpinv;
+    hipError_t e = hipMemsetAsync(d_meta, 0, sizeof(BaMeta), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ba->cost[0], 0, 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)P * 4, ctx->stream);
+    if (e != hipSuccess) { vo_set_error("vo_ba_create_filtered: memset failed: %s", hipGetErrorString(e)); return fail(VO_EHIP); }
+    const unsigned ob = (unsigned)((O + 255) / 256);
+    if (O) {
+        hipLaunchKernelGGL((ba_kernel<false>), dim3((unsigned)((O + BA_THREADS - 1) / BA_THREADS)), dim3(BA_THREADS), 0, ctx->stream,
+                           (const double *)ba->x[0], F, P, d_ci, d_pi, d_obs, O, ba->K, 0, ba->r, ba->cost[0], (double *)nullptr,
+                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL(ba_keep_kernel, dim3(ob), dim3(256), 0, ctx->stream, (const double *)ba->r, d_ci, d_pi, O, F, P, max_sq_error,
+                           d_keep, d_meta);
+        hipLaunchKernelGGL(ba_scan_sums_kernel, dim3(nblk_o), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_keep, O, d_bsum);
+        hipLaunchKernelGGL(ba_scan_offsets_kernel, dim3(1), dim3(BA_SCAN), 0, ctx->stream, d_bsum, nblk_o);
+        hipLaunchKernelGGL(ba_scan_finish_kernel, dim3(nblk_o), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_keep, O, (const int *)d_bsum, d_pos);
+        hipLaunchKernelGGL(ba_compact_kernel, dim3(ob), dim3(256), 0, ctx->stream, (const int *)d_keep, (const int *)d_pos, d_ci, d_pi, d_obs, O,
+                           n_frozen_cams, ba->ci, ba->pi, ba->cam32, ba->obs, d_meta);
+        hipLaunchKernelGGL(ba_lists_count_kernel, dim3(ob), dim3(256), 0, ctx->stream, (const int64_t *)ba->pi, (const int *)ba->cam32, d_meta,
+                           d_cnt, d_slot);
+    }
+    hipLaunchKernelGGL(ba_scan_sums_kernel, dim3(nblk_p), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_cnt, P, d_bsum);
+    hipLaunchKernelGGL(ba_scan_offsets_kernel, dim3(1), dim3(BA_SCAN), 0, ctx->stream, d_bsum, nblk_p);
+    hipLaunchKernelGGL(ba_scan_finish_kernel, dim3(nblk_p), dim3(BA_SCAN), 0, ctx->stream, (const int *)d_cnt, P, (const int *)d_bsum, ba->pptr);
+    if (O) {
+        hipLaunchKernelGGL(ba_lists_fill_kernel, dim3(ob), dim3(256), 0, ctx->stream, (const int64_t *)ba->pi, (const BaMeta *)d_meta,
+                           (const int *)ba->pptr, (const int *)d_slot, ba->pobs);
+        hipLaunchKernelGGL(ba_lists_sort_kernel, dim3((P + 3) / 4), dim3(256), 0, ctx->stream, P, (const int *)ba->pptr, ba->pobs);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { vo_set_error("vo_ba_create_filtered: launch failed: %s", hipGetErrorString(e)); return fail(VO_EHIP); }
+    BaMeta meta = {};
+    if ((rc = vo_result(ctx, &meta, d_meta, sizeof(meta))) || (rc = vo_results_finish(ctx))) return fail(rc);
+    if (meta.bad) {
+        vo_set_error("vo_ba_create_filtered: observation %d has an index out of range", meta.bad - 1);
+        return fail(VO_EINVAL);
+    }
+    ba->O = O ? meta.kept : 0;
+    ba->obs_start = O ? meta.frozen : 0;
+    ba->cam_first = (O && meta.kept > meta.frozen) ? meta.cam_first : F;
+    ba_configure(ba);
+    *n_kept = ba->O;
+    *obs_start = ba->obs_start;
+    *out = ba;
+    return VO_OK;
 }
 
 extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost)

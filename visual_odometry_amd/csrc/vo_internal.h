@@ -55,6 +55,9 @@ struct vo_ctx {
     size_t res_off = 0;
     struct { void *dst; const char *src; size_t bytes; } res_pending[16];
     int res_count = 0;
+    // device pool of the last destroyed bundle-adjustment solver, handed to the next one that fits (vo_ba_create)
+    char *ba_pool = nullptr;
+    size_t ba_pool_bytes = 0;
 };
 
 bool vo_ctx_is_live(const vo_ctx *ctx);

@@ -731,6 +731,37 @@ class BaSolver:
         self.handle = h
         _live_objects.add(self)
 
+    @classmethod
+    def filtered(cls, ctx: Context, F: int, P: int, ci, pi, obs, K, x0, max_sq_error: float, n_frozen_cams: int) -> "BaSolver":
+        """Solver of the observations that survive the outlier pre-filter at x0 (vo_ba_create_filtered): residual,
+        filter, compaction and landmark lists on the device, one upload of the observations.  ci, pi, obs, x0: numpy
+        (int64, int64, float64 or float32 (O,2), float64 6F+3P).  The result's .O and .obs_start describe the kept observations."""
+        self = cls.__new__(cls)
+        self.ctx, self.F, self.P = ctx, int(F), int(P)
+        self.handle = None
+        Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+        ci = np.ascontiguousarray(ci, np.int64).ravel()
+        pi = np.ascontiguousarray(pi, np.int64).ravel()
+        obs = np.asarray(obs)
+        f32 = obs.dtype == np.float32               # the pipeline's keypoints: sent as they are, widened on the device
+        obs = np.ascontiguousarray(obs, np.float32 if f32 else np.float64).reshape(-1, 2)
+        x0 = np.ascontiguousarray(x0, np.float64).ravel()
+        O = int(ci.size)
+        if int(pi.size) != O or int(obs.shape[0]) != O:
+            raise ValueError("BaSolver.filtered: ci, pi and obs differ in length")
+        if int(x0.size) != 6 * self.F + 3 * self.P:
+            raise ValueError(f"BaSolver.filtered: x0 has {x0.size} entries, expected {6 * self.F + 3 * self.P}")
+        h = ctypes.c_void_p()
+        kept, start = ctypes.c_int32(), ctypes.c_int32()
+        check(ctx.lib.vo_ba_create_filtered(ctx.handle, self.F, self.P, O, _ptr(ci), _ptr(pi), _ptr(obs), int(f32),
+                                            Kd.ctypes.data_as(_lib.c_f64p), _ptr(x0), float(max_sq_error), int(n_frozen_cams),
+                                            VO_MEM_HOST, ctypes.byref(h), ctypes.byref(kept), ctypes.byref(start)),
+              "vo_ba_create_filtered")
+        self.handle = h
+        self.O, self.obs_start = int(kept.value), int(start.value)
+        _live_objects.add(self)
+        return self
+
     def linearize(self, x) -> float:
         """Set the current parameter vector (6F+3P float64) and build residual + normal equations; returns the cost."""
         cost = ctypes.c_double()

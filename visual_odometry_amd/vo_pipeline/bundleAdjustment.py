@@ -119,13 +119,14 @@ class BundleAdjustment:
         """
         camera_indices = np.asarray(camera_indices, np.int64)
         point_indices = np.asarray(point_indices, np.int64)
-        keypoints, camera_indices, point_indices = self._preprocess_data(M, landmarks, camera_indices, point_indices,
-                                                                         keypoints)
         F, P = M.shape[0], landmarks.shape[0]
         x = np.hstack((self._camera_params(M).ravel(), np.asarray(landmarks, np.float64).ravel()))
-        obs = np.asarray(keypoints, np.float64)
-        start = self._obs_start(F, camera_indices)
-        x = self._levenberg_marquardt(x, F, P, camera_indices, point_indices, obs, start, max_iters, ftol)
+        if camera_indices.size and F and P:
+            # the outlier pre-filter of _preprocess_data, the compaction of what it keeps and the solver's observation
+            # lists in one library call: the observations cross to the device once
+            solver = hip.BaSolver.filtered(_runtime.context(), F, P, camera_indices, point_indices,
+                                           keypoints, self.K, x, params.BA_DISTANCE_TH, int(F / 4) + 1)
+            x = self._levenberg_marquardt(x, solver, max_iters, ftol)
         cams = x[:6 * F].reshape(F, 6)
         adjusted_M = np.zeros(M.shape)
         adjusted_M[:, :, 3] = cams[:, 3:]
@@ -133,13 +134,13 @@ class BundleAdjustment:
             adjusted_M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
         return adjusted_M, x[6 * F:].reshape(landmarks.shape).copy()
 
-    def _levenberg_marquardt(self, x, F, P, ci, pi, obs, start, max_iters, ftol):
+    def _levenberg_marquardt(self, x, solver, max_iters, ftol):
         """LM loop on the device-resident solver: every trial step (Schur complement, reduced solve,
-        back-substitution, re-linearisation) runs on the GPU; the host only compares two costs."""
-        if ci.size == 0:
-            return x
-        solver = hip.BaSolver(_runtime.context(), F, P, ci, pi, obs, self.K, start)
+        back-substitution, re-linearisation) runs on the GPU; the host only compares two costs.
+        Closes the solver."""
         try:
+            if solver.O == 0:
+                return x
             cost = solver.linearize(x)
             lam = 1e-3
             for _ in range(max_iters):
