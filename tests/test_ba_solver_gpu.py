@@ -178,6 +178,17 @@ def test_filtered_solver_equals_host_prefilter(ctx, F, P, vis, n_bad):
         assert a.linearize(x0) == pytest.approx(b.linearize(x0), rel=1e-12)
     finally:
         a.close(); b.close()
+    # device-resident inputs (float64 and float32 observations)
+    import torch
+    for o in (obs, o32):
+        a = hip.BaSolver.filtered(ctx, F, P, ci, pi, o, K, x0, params.BA_DISTANCE_TH, n_frozen)
+        b = hip.BaSolver.filtered(ctx, F, P, torch.from_numpy(ci).cuda(), torch.from_numpy(pi).cuda(), torch.from_numpy(o).cuda(), K,
+                                  torch.from_numpy(x0).cuda(), params.BA_DISTANCE_TH, n_frozen)
+        try:
+            assert (a.O, a.obs_start) == (b.O, b.obs_start)
+            assert a.linearize(x0) == pytest.approx(b.linearize(x0), rel=1e-12)
+        finally:
+            a.close(); b.close()
     # the drop-in class takes the device route
     if F >= 4:
         from scipy.spatial.transform import Rotation

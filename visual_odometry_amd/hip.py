@@ -734,28 +734,39 @@ class BaSolver:
     @classmethod
     def filtered(cls, ctx: Context, F: int, P: int, ci, pi, obs, K, x0, max_sq_error: float, n_frozen_cams: int) -> "BaSolver":
         """Solver of the observations that survive the outlier pre-filter at x0 (vo_ba_create_filtered): residual,
-        filter, compaction and landmark lists on the device, one upload of the observations.  ci, pi, obs, x0: numpy
-        (int64, int64, float64 or float32 (O,2), float64 6F+3P).  The result's .O and .obs_start describe the kept observations."""
+        filter, compaction and landmark lists on the device, one upload of the observations.  ci, pi, obs, x0: numpy arrays or
+        torch tensors on the context's device (int64, int64, float64 or float32 (O,2), float64 6F+3P).  The result's .O and .obs_start describe the kept observations."""
         self = cls.__new__(cls)
         self.ctx, self.F, self.P = ctx, int(F), int(P)
         self.handle = None
         Kd = np.ascontiguousarray(K, np.float64).reshape(9)
-        ci = np.ascontiguousarray(ci, np.int64).ravel()
-        pi = np.ascontiguousarray(pi, np.int64).ravel()
-        obs = np.asarray(obs)
-        f32 = obs.dtype == np.float32               # the pipeline's keypoints: sent as they are, widened on the device
-        obs = np.ascontiguousarray(obs, np.float32 if f32 else np.float64).reshape(-1, 2)
-        x0 = np.ascontiguousarray(x0, np.float64).ravel()
-        O = int(ci.size)
-        if int(pi.size) != O or int(obs.shape[0]) != O:
+        if _is_torch(ci):
+            import torch
+            if not (_is_torch(pi) and _is_torch(obs) and _is_torch(x0)):
+                raise ValueError("BaSolver.filtered: ci, pi, obs and x0 must live in the same memory")
+            if ci.dtype != torch.int64 or pi.dtype != torch.int64 or obs.dtype not in (torch.float32, torch.float64) or \
+                    x0.dtype != torch.float64:
+                raise ValueError("BaSolver.filtered: device inputs must be int64 indices, float32/float64 observations, float64 x0")
+            ci, pi, obs, x0 = ci.contiguous(), pi.contiguous(), obs.contiguous(), x0.contiguous()
+            f32 = obs.dtype == torch.float32
+            O, n_obs, n_pi, n_x, mem = int(ci.numel()), int(obs.numel()) // 2, int(pi.numel()), int(x0.numel()), VO_MEM_DEVICE
+        else:
+            ci = np.ascontiguousarray(ci, np.int64).ravel()
+            pi = np.ascontiguousarray(pi, np.int64).ravel()
+            obs = np.asarray(obs)
+            f32 = obs.dtype == np.float32               # the pipeline's keypoints: sent as they are, widened on the device
+            obs = np.ascontiguousarray(obs, np.float32 if f32 else np.float64).reshape(-1, 2)
+            x0 = np.ascontiguousarray(x0, np.float64).ravel()
+            O, n_obs, n_pi, n_x, mem = int(ci.size), int(obs.shape[0]), int(pi.size), int(x0.size), VO_MEM_HOST
+        if n_pi != O or n_obs != O:
             raise ValueError("BaSolver.filtered: ci, pi and obs differ in length")
-        if int(x0.size) != 6 * self.F + 3 * self.P:
-            raise ValueError(f"BaSolver.filtered: x0 has {x0.size} entries, expected {6 * self.F + 3 * self.P}")
+        if n_x != 6 * self.F + 3 * self.P:
+            raise ValueError(f"BaSolver.filtered: x0 has {n_x} entries, expected {6 * self.F + 3 * self.P}")
         h = ctypes.c_void_p()
         kept, start = ctypes.c_int32(), ctypes.c_int32()
         check(ctx.lib.vo_ba_create_filtered(ctx.handle, self.F, self.P, O, _ptr(ci), _ptr(pi), _ptr(obs), int(f32),
                                             Kd.ctypes.data_as(_lib.c_f64p), _ptr(x0), float(max_sq_error), int(n_frozen_cams),
-                                            VO_MEM_HOST, ctypes.byref(h), ctypes.byref(kept), ctypes.byref(start)),
+                                            mem, ctypes.byref(h), ctypes.byref(kept), ctypes.byref(start)),
               "vo_ba_create_filtered")
         self.handle = h
         self.O, self.obs_start = int(kept.value), int(start.value)
