@@ -188,61 +188,67 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
     // ba_cam_sum_kernel adds the copies up.
     // (this section comes before the global stores and atomics of the wave: its wavefront fence waits for
     // every outstanding memory operation of the wave, and behind those writes it cost 25 us of 60 at one window)
-    const unsigned long long act = __ballot(active);
-    if (act != 0) {
-        double *rep = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42;
-        const int first = __ffsll((long long)act) - 1;
-        const long long c0 = __shfl((long long)c, first);
-        const bool uniform_cam = __ballot(active && c != c0) == 0;
-        if (uniform_cam) {
+    // One pass per camera present among the wave's active lanes (the caller's observations are sorted by camera, so
+    // that is one pass, two for the wave that straddles a camera boundary): the other cameras' lanes add zeros.
+    // A wave that left its mixed lanes to per-lane atomics put up to 64 atomics of one instruction on the same
+    // address, which the memory system takes one after the other -- nine such waves of 784 were half of the
+    // kernel's time at one window.
+    unsigned long long todo = __ballot(active);
+    if constexpr (WITH_J) {
+        __shared__ double red[BA_THREADS / 64][8][65];
+        double(*mine)[65] = red[threadIdx.x >> 6];
+        constexpr int TA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        constexpr int TB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+        const int v = lane & 7, seg = lane >> 3;
+        for (int pass = 0; todo != 0 && pass < 4; ++pass) {
+            const int first = __ffsll((long long)todo) - 1;
+            const long long c0 = __shfl((long long)c, first);
+            const bool here = active && c == c0;
+            todo &= ~__ballot(here);
+            double *rep = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42;
+            double *hc = rep + 42 * c0;
             // 21 upper-triangle entries of Jc^T Jc and 6 of Jc^T r, eight terms at a time: every lane parks its
             // terms in LDS (row per term, column per lane), a lane adds up an eighth of one row, three shuffles
             // join the eighths, and eight lanes issue the atomics (mirroring the off-diagonal entries).  Eight
             // rows per wave rather than all 27 keep the workgroup at 16 KB of LDS: with 56 KB only two waves
             // fitted a SIMD, and at many windows the kernel waited on memory with nothing else to run.
-            if constexpr (WITH_J) {
-                __shared__ double red[BA_THREADS / 64][8][65];
-                double(*mine)[65] = red[threadIdx.x >> 6];
-                constexpr int TA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-                constexpr int TB[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-                const int v = lane & 7, seg = lane >> 3;
-                double *hc = rep + 42 * c0;
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
+            for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e = 8 * ch + k, et = e < 21 ? e : 0, eg = e < 21 ? 0 : (e < 27 ? e - 21 : 0);
-                        if (e < 21) mine[k][lane] = Jc[TA[et]] * Jc[TB[et]] + Jc[6 + TA[et]] * Jc[6 + TB[et]];
-                        else if (e < 27) mine[k][lane] = Jc[eg] * rr[0] + Jc[6 + eg] * rr[1];
-                    }
-                    // the rows are read by other lanes of the same wavefront: only the LDS writes have to have
-                    // landed (a wavefront-scope fence would also wait for the wave's global stores)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    const double *row = &mine[v][seg * 8];
-                    double part = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
-                    part += __shfl_xor(part, 8);
-                    part += __shfl_xor(part, 16);
-                    part += __shfl_xor(part, 32);
-                    const int e = 8 * ch + v;
-                    if (seg == 0 && e < 27) {
-                        if (e < 21) {
-                            // term index -> (a, b) of the upper triangle, row-major
-                            const int ta = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
-                            const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
-                            const int tb = ta + (e - first_of_row);
-                            unsafeAtomicAdd(hc + ta * 6 + tb, part);
-                            if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, part);
-                        } else {
-                            unsafeAtomicAdd(hc + 36 + (e - 21), part);
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's reads are in before the next one's writes
-                    __builtin_amdgcn_wave_barrier();
+                for (int k = 0; k < 8; ++k) {
+                    const int e = 8 * ch + k, et = e < 21 ? e : 0, eg = e < 21 ? 0 : (e < 27 ? e - 21 : 0);
+                    if (e < 21) mine[k][lane] = here ? Jc[TA[et]] * Jc[TB[et]] + Jc[6 + TA[et]] * Jc[6 + TB[et]] : 0.0;
+                    else if (e < 27) mine[k][lane] = here ? Jc[eg] * rr[0] + Jc[6 + eg] * rr[1] : 0.0;
                 }
+                // the rows are read by other lanes of the same wavefront: only the LDS writes have to have
+                // landed (a wavefront-scope fence would also wait for the wave's global stores)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const double *row = &mine[v][seg * 8];
+                double part = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
+                part += __shfl_xor(part, 8);
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                const int e = 8 * ch + v;
+                if (seg == 0 && e < 27) {
+                    if (e < 21) {
+                        // term index -> (a, b) of the upper triangle, row-major
+                        const int ta = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+                        const int first_of_row = ta == 0 ? 0 : ta == 1 ? 6 : ta == 2 ? 11 : ta == 3 ? 15 : ta == 4 ? 18 : 20;
+                        const int tb = ta + (e - first_of_row);
+                        unsafeAtomicAdd(hc + ta * 6 + tb, part);
+                        if (tb != ta) unsafeAtomicAdd(hc + tb * 6 + ta, part);
+                    } else {
+                        unsafeAtomicAdd(hc + 36 + (e - 21), part);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this chunk's reads are in before the next one's writes
+                __builtin_amdgcn_wave_barrier();
             }
-        } else if (active) {
-            double *hc = rep + 42 * c;
+        }
+        // observations in no camera order: after four cameras the rest of the wave adds its terms lane by lane
+        if (todo != 0 && active && ((todo >> lane) & 1ull)) {
+            double *hc = cam_rep + (size_t)(blockIdx.x % BA_REPLICAS) * F * 42 + 42 * c;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
