@@ -1119,12 +1119,24 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, in
     const int lane = threadIdx.x & 63;
     const int waves = SCHUR_THREADS / 64;
     for (int p = blockIdx.x * waves + (threadIdx.x >> 6); p < P; p += gridDim.x * waves) {
+        const int o0 = pptr[p], k = pptr[p + 1] - o0;
+        if (!first) {
+            // a landmark is seen by a run of neighbouring cameras, so most strips hold none of its rows: look at its
+            // cameras first and leave before the inverse and the block reads (the first strip also writes the
+            // inverses and the right-hand side of every landmark, so it visits them all)
+            bool hit = false;
+            for (int a0 = 0; a0 < k; a0 += 64)
+                if (a0 + lane < k) {
+                    const int ca = cam[pobs[o0 + a0 + lane]];
+                    hit = hit || (ca >= c0 && ca < c1);
+                }
+            if (__ballot(hit) == 0) continue;
+        }
         double inv[9];
         bool dead;
         damped_point_inverse(Hpp + 9 * (int64_t)p, lambda, inv, dead);
         if (first && lane < 9) Dpinv[9 * (int64_t)p + lane] = inv[lane];
         if (dead) continue;  // no Jacobian rows: every Hcp block of this landmark is zero
-        const int o0 = pptr[p], k = pptr[p + 1] - o0;
         const double *gp = g + 6 * (int64_t)F + 3 * (int64_t)p;
         const double u0 = inv[0] * gp[0] + inv[1] * gp[1] + inv[2] * gp[2];
         const double u1 = inv[3] * gp[0] + inv[4] * gp[1] + inv[5] * gp[2];
