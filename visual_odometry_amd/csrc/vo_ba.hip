@@ -1888,7 +1888,9 @@ static void ba_configure(vo_ba *ba)
     // keep the reduced system in LDS when it fits (up to the 160 KB of a gfx950 CU)
     const size_t need = (n * n + 2 * n) * 8;
     ba->lds_bytes = 0;
-    if (need <= 60 * 1024) ba->lds_bytes = need;
+    const char *nolds = getenv("VO_BA_NO_LDS");                 // comparison runs: keep even a small reduced system in global memory
+    if (nolds && nolds[0] == '1') { /* fall through to the global-memory kernels */ }
+    else if (need <= 60 * 1024) ba->lds_bytes = need;
     else if (need + 1024 <= 160 * 1024 &&
              hipFuncSetAttribute((const void *)ba_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess &&
              hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
