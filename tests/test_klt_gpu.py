@@ -271,3 +271,31 @@ def test_klt_malaga_shapes_3000_keypoints(oracle, ctx, klt_kernel, shape, levels
     agree, d, n_both, _ = _compare(oracle, ctx, img0, img1, pts, max_level=8)
     assert n_both > 2500
     assert agree >= STATUS_AGREE and d <= POS_TOL, (agree, d)
+
+
+def test_klt_translation_equivariance_full_size(ctx, klt_kernel):
+    """A property that needs no checker and holds at the benchmark's full size: cropping both frames by a multiple of
+    2^maxLevel pixels shifts every pyramid level by whole pixels, so keypoints far enough from the borders (the
+    pyramid's and the window's reach at the coarsest level) see the same pixels in both runs and must come out at the
+    same place, shifted by the crop -- up to the float32 rounding of coordinates that differ by the shift (observed
+    5e-4 px on 0.5 % of the coordinates, where an iteration's stopping test falls the other way)."""
+    import os
+    import sys
+    from visual_odometry_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    frames, _ = bench.make_streams([5], 2)
+    img0, img1 = frames[0, 0], frames[1, 0]
+    dy, dx = 16, 24                                   # multiples of 2^3
+    H, W = img0.shape
+    reach = 140                                       # > 2^3 * (window half 11 + flow + filter taps) pixels at level 0
+    rng = np.random.default_rng(3)
+    n = 2000
+    p = np.stack([rng.uniform(reach + dx, W - reach, n), rng.uniform(reach + dy, H - reach, n)], axis=1).astype(np.float32)
+    full = [hip.Pyramid(ctx, 1, H, W, bench.MAX_LEVEL).build(im) for im in (img0, img1)]
+    out_a, st_a, err_a = hip.klt_track(ctx, full[0], full[1], p)
+    crop = [hip.Pyramid(ctx, 1, H - dy, W - dx, bench.MAX_LEVEL).build(np.ascontiguousarray(im[dy:, dx:])) for im in (img0, img1)]
+    out_b, st_b, err_b = hip.klt_track(ctx, crop[0], crop[1], p - np.float32([dx, dy]))
+    assert (st_a[0] == st_b[0]).all() and st_a[0].mean() > 0.99
+    np.testing.assert_allclose(out_a[0] - np.float32([dx, dy]), out_b[0], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(err_a[0], err_b[0], rtol=1e-3, atol=1e-6)      # min-eigenvalues: same template pixels
