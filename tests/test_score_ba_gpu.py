@@ -175,3 +175,28 @@ def test_ba_many_windows_default_switch(oracle, ctx):
         got = ne[k].cpu().numpy()
         assert np.abs(got - ref[k]).max() <= 1e-10 * np.abs(ref[k]).max(), k
     assert torch.equal(ne["Hpp"], ne2["Hpp"]) and torch.equal(ne["g"][6 * F * Wn:], ne2["g"][6 * F * Wn:])   # ordered sums
+
+
+def test_score_properties_full_size(ctx):
+    """Properties of the scoring rules that need no checker, at the full RANSAC configuration (3000 correspondences,
+    2048 hypotheses): counts are the row sums of the masks; a fundamental matrix scaled by a power of two scores the
+    same (every product scales exactly, the error is a ratio); permuting the correspondences permutes the mask columns;
+    permuting the hypotheses permutes counts and rows."""
+    from visual_odometry_amd import hip
+    n, H = 3000, 2048
+    sc = synth.two_view_scene(n=n, seed=21)
+    Fh = synth.fundamental_hypotheses(sc, H, seed=21)
+    c, m = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh, 0.1)
+    np.testing.assert_array_equal(c, m.sum(axis=1))
+    c4, m4 = hip.score_fundamental(ctx, sc["m1"], sc["m2"], Fh * 4.0, 0.1)
+    np.testing.assert_array_equal(c4, c); np.testing.assert_array_equal(m4, m)
+    rng = np.random.default_rng(0)
+    pp, ph = rng.permutation(n), rng.permutation(H)
+    cp, mp = hip.score_fundamental(ctx, sc["m1"][pp], sc["m2"][pp], Fh[ph], 0.1)
+    np.testing.assert_array_equal(cp, c[ph]); np.testing.assert_array_equal(mp, m[ph][:, pp])
+    Rt = synth.pose_hypotheses(sc, H, seed=21)
+    c, m = hip.score_pnp(ctx, sc["X"], sc["m2"], sc["K"], Rt, 1.0)
+    np.testing.assert_array_equal(c, m.sum(axis=1))
+    cp, mp = hip.score_pnp(ctx, sc["X"][pp], sc["m2"][pp], sc["K"], Rt[ph], 1.0)
+    np.testing.assert_array_equal(cp, c[ph]); np.testing.assert_array_equal(mp, m[ph][:, pp])
+    assert c.max() > 0.5 * n
