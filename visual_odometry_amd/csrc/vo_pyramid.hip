@@ -65,16 +65,20 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
     const int cx = 2 * ox - 2;                          // first input column of the lane's window
     const bool inrow = cx >= 0 && cx + 12 <= sw;
     const int colbase = min(max(cx, 0), sw - 12);       // the launch requires sw >= 12
-    const uint8_t *simg = src + (int64_t)img * sstride + colbase;
+    // Addresses as the image's base (wave-uniform: scalar registers) plus one unsigned 32-bit offset per lane -- the
+    // build checks that a level's pitch fits 24 bits and an image 32 -- formed with the 24-bit multiply: written with
+    // 64-bit products, the nineteen row addresses of a lane were 84 quarter-rate multiplies, a fifth of the kernel's
+    // vector time.
+    const uint8_t *simg = src + (int64_t)img * sstride;
+    const unsigned sp = (unsigned)spitch;
 
     uint32_t w[PR_ROWS][3];
 #pragma unroll
     for (int k = 0; k < PR_ROWS; ++k) {
         int y = 2 * oy0 - 2 + k;
-        y = y < 0 ? -y : y;
-        y = y >= sh ? 2 * sh - 2 - y : y;
-        y = min(max(y, 0), sh - 1);                      // rows needed only by outputs below the image
-        const uint8_t *row = simg + (int64_t)y * spitch;
+        const int a = max(y, -y);                        // REFLECT_101 for one fold, clamped (rows needed only by
+        y = max(min(a, 2 * sh - 2 - a), 0);              // outputs below the image)
+        const uint8_t *row = simg + (__umul24((unsigned)y, sp) + (unsigned)colbase);
         __builtin_memcpy(&w[k][0], row, 4);
         __builtin_memcpy(&w[k][1], row + 4, 4);
         __builtin_memcpy(&w[k][2], row + 8, 4);
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
     }
 
     pd_u16x2 h[5][2];
-    uint8_t *dimg = dst + (int64_t)img * dstride + ox;
+    uint8_t *dimg = dst + (int64_t)img * dstride;
+    const unsigned dp = (unsigned)dpitch;
 #pragma unroll
     for (int k = 0; k < PR_ROWS; ++k) {
         uint32_t n0 = w[k][0], n1 = w[k][1], n2 = w[k][2];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
             }
             // bytes past dw land in the row's pitch padding
             if (gy < dh)
-                *reinterpret_cast<uint32_t *>(dimg + (int64_t)gy * dpitch) = __builtin_amdgcn_perm(out2[1], out2[0], 0x06040200u);
+                *reinterpret_cast<uint32_t *>(dimg + (__umul24((unsigned)gy, dp) + (unsigned)ox)) = __builtin_amdgcn_perm(out2[1], out2[0], 0x06040200u);
         }
     }
 }
