@@ -966,6 +966,7 @@ struct vo_ba {
     int cur = 0;
     bool linearized = false, have_candidate = false;
     size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
+    size_t solve6_lds = 0; // LDS of the camera-at-a-time solve of such a system (0: the column-at-a-time kernel)
     int solve_w = 0;       // panel width of the blocked solve of a system that is not (0: the column-at-a-time kernel)
     size_t solve_lds = 0;
     int cam_first = 0;     // cameras below this one have no observation with Jacobian rows
@@ -1262,6 +1263,161 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, d
     if (tid == 0) flag[0] = 1;
 }
 
+
+// ba_solve_kernel<true> one camera (six columns) at a time.  A column step of the kernel above is a rank-1 update of
+// the whole trailing matrix and a barrier, 6F of them, and the back-substitution another 6F barriers; LDS latency and
+// the barriers are its time, not arithmetic.  Here a step takes a camera's six columns: every lane factorises the 6x6
+// diagonal block for itself in registers (no hand-over), a lane per row eliminates that row's six entries against it
+// and parks the scaled row beside the matrix, and the trailing matrix takes one rank-6 update in 2x2 register tiles:
+// two barriers per camera.  The back-substitution is blocked the same way, one barrier per camera.  Same LDL^T, same
+// unscaled columns, same treatment of cameras without Jacobian rows and of a non-positive pivot.
+#define SOLVE6_LD(n) ((n) | 1)              // odd row pitch: a column's entries fall on different LDS banks
+__global__ __launch_bounds__(SOLVE_THREADS) void ba_solve6_kernel(int n, int F, const double *__restrict__ S,
+                                                                  const double *__restrict__ rhs, const double *__restrict__ Hcc,
+                                                                  const double *__restrict__ g, double lambda,
+                                                                  double *__restrict__ dc, int *__restrict__ flag)
+{
+    extern __shared__ double sl[];
+    __shared__ unsigned char dead_cam[256];
+    const int ld = SOLVE6_LD(n), tid = threadIdx.x;
+    // rows 0 .. n-1 of the matrix, row n = the right-hand side; then 1 / pivots; then the scaled rows of the current camera
+    double *A = sl, *dinv = sl + (size_t)(n + 1) * ld, *Lp = dinv + n;
+    for (int c = tid; c < F; c += SOLVE_THREADS) {
+        double sabs = 0;
+        for (int k = 0; k < 36; ++k) sabs += fabs(Hcc[36 * (int64_t)c + k]);
+        dead_cam[c] = sabs == 0;
+    }
+    for (int i = tid; i < n * n; i += SOLVE_THREADS) {
+        const int r = i / n, c = i - r * n;
+        A[(size_t)r * ld + c] = S[i];
+    }
+    for (int i = tid; i < n; i += SOLVE_THREADS) A[(size_t)n * ld + i] = rhs[i] - g[i];
+    __syncthreads();
+    for (int t = tid; t < F * 36; t += SOLVE_THREADS) {
+        const int c = t / 36, e = t - c * 36, i = e / 6, j = e - i * 6;
+        const bool dead = dead_cam[c];
+        double v = Hcc[t];
+        if (i == j) v += lambda * v + 1e-12;
+        if (dead) v = (i == j) ? 1.0 : 0.0;
+        const size_t at = (size_t)(6 * c + i) * ld + 6 * c + j;
+        A[at] = dead ? v : A[at] + v;
+    }
+    __syncthreads();
+    bool ok = true;
+    for (int kb = 0; kb < n && ok; kb += 6) {
+        // the camera's diagonal block, lower triangle, in every lane's registers: q[r][c] = unscaled column entry
+        double q[6][6], id[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) q[r][c] = A[(size_t)(kb + r) * ld + kb + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double d = q[c][c];
+            ok = ok && d > 0.0;
+            id[c] = 1.0 / (ok ? d : 1.0);
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                const double f = q[r][c] * id[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 <= r; ++c2) q[r][c2] -= f * q[c2][c];
+            }
+        }
+        if (!ok) break;                                      // the same in every lane
+        // rows below the block (and the right-hand side): eliminate the six entries, keep them (unscaled) in place and
+        // the scaled ones in Lp
+        for (int i = kb + 6 + tid; i <= n; i += SOLVE_THREADS) {
+            double x[6];
+            double *row = A + (size_t)i * ld + kb;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[c] = row[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double f = x[c] * id[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < 6; ++c2) x[c2] -= f * q[c2][c];
+                Lp[(size_t)i * 6 + c] = f;
+                row[c] = x[c];
+            }
+        }
+        __syncthreads();
+        // every lane has read the diagonal block by now: its factored entries (the back-substitution reads them; the
+        // update below touches rows and columns after the block only) and the reciprocal pivots go back
+        if (tid < 6) {
+            double dv = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dv = c == tid ? id[c] : dv;
+            dinv[kb + tid] = dv;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= tid) {
+                    double v = 0;
+#pragma unroll
+                    for (int r = c; r < 6; ++r) v = r == tid ? q[r][c] : v;
+                    A[(size_t)(kb + tid) * ld + kb + c] = v;
+                }
+        }
+        // trailing rank-6 update, 2 x 2 tiles of the lower triangle (row n = right-hand side takes part as a row)
+        const int m = n + 1 - (kb + 6), tiles = (m + 1) / 2;     // rows / columns left, in tiles of two
+        for (int t = tid; t < tiles * tiles; t += SOLVE_THREADS) {
+            const int ti = t / tiles, tj = t - ti * tiles;
+            if (tj > ti) continue;
+            const int i0 = kb + 6 + 2 * ti, j0 = kb + 6 + 2 * tj;
+            const int i1 = min(i0 + 1, n), j1 = min(j0 + 1, n - 1);
+            if (j0 > n - 1) continue;                             // the right-hand side is a row only
+            double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double l0 = Lp[(size_t)i0 * 6 + c], l1 = Lp[(size_t)i1 * 6 + c];
+                const double u0 = A[(size_t)j0 * ld + kb + c], u1 = A[(size_t)j1 * ld + kb + c];
+                a00 += l0 * u0; a01 += l0 * u1; a10 += l1 * u0; a11 += l1 * u1;
+            }
+            A[(size_t)i0 * ld + j0] -= a00;
+            if (j1 != j0 && j1 <= i0) A[(size_t)i0 * ld + j1] -= a01;
+            if (i1 != i0) {
+                A[(size_t)i1 * ld + j0] -= a10;
+                if (j1 != j0 && j1 <= i1) A[(size_t)i1 * ld + j1] -= a11;
+            }
+        }
+        __syncthreads();
+    }
+    if (!ok) {
+        if (tid == 0) flag[0] = 0;
+        for (int i = tid; i < n; i += SOLVE_THREADS) dc[i] = 0.0;
+        return;
+    }
+    // row n holds z = L^-1 rhs; y = D^-1 z; L^T x = y, a camera at a time from the last
+    double *b = A + (size_t)n * ld;
+    for (int i = tid; i < n; i += SOLVE_THREADS) b[i] *= dinv[i];
+    __syncthreads();
+    for (int kb = n - 6; kb >= 0; kb -= 6) {
+        // the camera's six unknowns, in every lane: x_k = y_k - sum_{i > k in the block} L_ik x_i, L_ik = A[i][k] / d_k
+        double x[6];
+#pragma unroll
+        for (int c = 5; c >= 0; --c) {
+            double v = b[kb + c];
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) v -= A[(size_t)(kb + r) * ld + kb + c] * dinv[kb + c] * x[r];
+            x[c] = v;
+        }
+        __syncthreads();                                      // every lane has read b[kb ..] before it is overwritten
+        if (tid < 6) {
+            double v = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v = c == tid ? x[c] : v;
+            b[kb + tid] = v;
+        }
+        for (int i = tid; i < kb; i += SOLVE_THREADS) {
+            double acc = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc += A[(size_t)(kb + c) * ld + i] * x[c];
+            b[i] -= acc * dinv[i];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SOLVE_THREADS) dc[i] = dead_cam[i / 6] ? 0.0 : b[i];
+    if (tid == 0) flag[0] = 1;
+}
 
 // The same factorisation for reduced systems that do not fit in LDS (more than 23 cameras: the reference's window
 // reaches back to its 20th-last keyframe and takes every frame since), still one workgroup, but blocked: a step
@@ -1896,6 +2052,15 @@ static void ba_configure(vo_ba *ba)
              hipFuncSetAttribute((const void *)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess)
         ba->lds_bytes = need;
     (void)hipGetLastError();
+    if (ba->lds_bytes) {
+        // matrix + right-hand side row at an odd pitch, 1 / pivots, six scaled entries per row
+        const size_t s6 = ((size_t)(n + 1) * SOLVE6_LD(n) + n + 6 * (n + 1)) * 8;
+        const char *env = getenv("VO_BA_SOLVE");              // "columns": the column-at-a-time kernel (comparison runs, tests)
+        if (!(env && env[0] == 'c') && s6 <= 160 * 1024 - 512 &&
+            (s6 <= 60 * 1024 || hipFuncSetAttribute((const void *)ba_solve6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s6) == hipSuccess))
+            ba->solve6_lds = s6;
+        (void)hipGetLastError();
+    }
     if (!ba->lds_bytes) {
         // panel (W columns of n + 1 rows), the pivots' reciprocals and the right-hand side in LDS
         const long budget = 150 * 1024 - 16 * (long)n;
@@ -2281,7 +2446,10 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
         hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(blocks), dim3(SCHUR_THREADS), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
                            ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
     VO_HIP_CHECK(hipGetLastError());
-    if (ba->lds_bytes)
+    if (ba->lds_bytes && ba->solve6_lds)
+        hipLaunchKernelGGL(ba_solve6_kernel, dim3(1), dim3(SOLVE_THREADS), ba->solve6_lds, ctx->stream, n, ba->F, (const double *)ba->S,
+                           (const double *)ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+    else if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
                            ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
     else if (ba->panels) {
