@@ -44,11 +44,13 @@ def _start(F, ci):
     return int(np.count_nonzero(ci < int(F / 4) + 1))
 
 
-# 6 cameras: reduced system in LDS; 16: LDS beyond the default 64 KB; 26 and more: reduced system kept in global memory
+# 6 cameras: reduced system in LDS (factorised a camera at a time, or column by column: "columns"); 16: LDS beyond the default
+# 64 KB; 22: the largest system the camera-at-a-time kernel takes; 23: the largest in LDS (column by column); 26 and more: reduced system kept in global memory
 # and factorised in panels, one launch per panel (26: 8 panels; 60: the size of the end-to-end run's shorter windows;
 # 101: its longer ones, a ragged last panel), or by the kernels kept for comparison: all panels in one workgroup
 # ("blocked") and column by column ("columns")
-@pytest.mark.parametrize("F,P,vis,solve", [(6, 150, 0.7, ""), (16, 300, 0.5, ""), (26, 200, 0.4, ""), (26, 200, 0.4, "columns"),
+@pytest.mark.parametrize("F,P,vis,solve", [(6, 150, 0.7, ""), (6, 150, 0.7, "columns"), (16, 300, 0.5, ""), (16, 300, 0.5, "columns"),
+                                           (22, 250, 0.5, ""), (23, 250, 0.5, ""), (26, 200, 0.4, ""), (26, 200, 0.4, "columns"),
                                            (26, 200, 0.4, "blocked"), (60, 400, 0.3, ""), (60, 400, 0.3, "blocked"),
                                            (101, 600, 0.3, "")])
 def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis, solve, monkeypatch):
