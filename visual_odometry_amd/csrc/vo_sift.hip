@@ -47,6 +47,11 @@
 
 struct SiftKernel { int n; float k[SIFT_MAX_TAPS + 1]; };
 struct SiftCand { int octave, layer, r, c; };
+struct SiftOctaves {
+    int n_oct, layers;
+    int w[SIFT_MAX_OCTAVES], h[SIFT_MAX_OCTAVES];
+    size_t gauss_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];   // float offsets into the pool
+};
 // descriptor job of one keypoint: image, rounded centre, rotation already divided by the histogram width
 struct SiftJob { int octave, layer, px, py, radius, out; float ori, cos_t, sin_t; };     // out: descriptor row
 
@@ -201,6 +206,86 @@ __global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__
     dog[plane * blockIdx.y + t] = a[plane + t] - a[t];
 }
 
+// The small octaves at the end of the scale space (a 1241 x 376 frame: 77 x 23 pixels and down) in one launch: a
+// launch per blur pass costs more than the pass itself there.  One workgroup walks the octaves and their layers in
+// order -- the first image of an octave is every second pixel of the previous octave's layer `layers`, layer i the
+// blur of layer i - 1 -- with the row and column sums in the order of sift_blur_rows_kernel / sift_blur_cols_kernel,
+// and writes the Gaussian images and their differences.  The current layer lives in LDS with its rows extended by
+// the reflected pixels at either end, the row pass's output with the reflected rows above and below, so a tap is
+// one LDS read, one multiplication and one addition; a thread owns the same (at most two) pixels throughout.
+#define SIFT_TAIL_PIXELS 2048       // an octave of at most this many pixels ...
+#define SIFT_TAIL_PADDED 6144       // ... and at most this many with the reflected borders on
+// A barrier between phases that exchange data through LDS only: it does not wait for global stores in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+struct SiftTail { int first, halo; SiftKernel K[SIFT_MAX_LAYERS + 3]; };      // K[i]: the blur that makes layer i from layer i - 1
+__global__ __launch_bounds__(1024) void sift_tail_octaves_kernel(float *__restrict__ pool, SiftOctaves O, SiftTail T)
+{
+    __shared__ float buf[2][SIFT_TAIL_PADDED];
+    __shared__ float tmp[SIFT_TAIL_PADDED];
+    const int tid = threadIdx.x, layers = O.layers, R = T.halo;
+    for (int o = T.first; o < O.n_oct; ++o) {
+        const int w = O.w[o], h = O.h[o], plane = w * h, pw = O.w[o - 1], wp = w + 2 * R;
+        float *g = pool + O.gauss_off[o], *dog = pool + O.dog_off[o];
+        const float *prev = pool + O.gauss_off[o - 1] + (size_t)pw * O.h[o - 1] * layers;
+        float *cur = buf[0], *nxt = buf[1];
+        int at[2], att[2];              // this thread's pixels in the row-extended and in the row-added layout
+        bool has[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 1024 * q, y = p / w, x = p - y * w;
+            has[q] = p < plane;
+            at[q] = y * wp + R + x;
+            att[q] = (y + R) * w + x;
+            if (has[q]) {
+                const float v = prev[(size_t)(2 * y) * pw + 2 * x];
+                cur[at[q]] = v;
+                g[p] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = 1; i < layers + 3; ++i) {
+            const SiftKernel &K = T.K[i];
+            const int r = K.n >> 1;
+            for (int e = tid; e < 2 * r * h; e += 1024) {              // r reflected pixels at either end of every row
+                const int y = e / (2 * r), k = e - y * 2 * r, x = k < r ? k - r : w + (k - r);
+                cur[y * wp + R + x] = cur[y * wp + R + reflect101(x, w)];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (has[q]) {
+                    const float *s = cur + at[q] - r;
+                    float acc = s[0] * K.k[0];
+                    for (int j = 1; j < K.n; ++j) acc += s[j] * K.k[j];
+                    tmp[att[q]] = acc;
+                }
+            lds_barrier();
+            for (int e = tid; e < 2 * r * w; e += 1024) {              // r reflected rows above and below
+                const int k = e / w, x = e - k * w, y = k < r ? k - r : h + (k - r);
+                tmp[(y + R) * w + x] = tmp[(reflect101(y, h) + R) * w + x];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (has[q]) {
+                    const float *c = tmp + att[q];
+                    float acc = K.k[r] * c[0];
+                    for (int j = 1; j <= r; ++j) acc += K.k[r + j] * (c[j * w] + c[-j * w]);
+                    const int p = tid + 1024 * q;
+                    nxt[at[q]] = acc;
+                    g[(size_t)plane * i + p] = acc;
+                    dog[(size_t)plane * (i - 1) + p] = acc - cur[at[q]];
+                }
+            lds_barrier();
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        __syncthreads();        // the next octave reads this one's layer `layers` from memory
+    }
+}
+
 // A workgroup tests 64 x 4 pixels of one layer.  It first stages the 66 x 6 neighbourhood of the layer and of its two
 // neighbours in LDS with coalesced reads that are all in flight at once (testing straight from memory made every
 // wavefront wait for three dependent rounds of reads: 185 us at the finest octave of a 1241 x 376 frame).
@@ -286,12 +371,6 @@ __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keyp
     const int words = s_n * (int)(sizeof(vo_sift_keypoint) / 8);
     for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
 }
-
-struct SiftOctaves {
-    int n_oct, layers;
-    int w[SIFT_MAX_OCTAVES], h[SIFT_MAX_OCTAVES];
-    size_t gauss_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];   // float offsets into the pool
-};
 
 // One wavefront per candidate.
 #define SIFT_ORI_CHUNK 1024
@@ -653,7 +732,20 @@ static int sift_build(vo_ctx *ctx, const uint8_t *d_img, int height, int width, 
     }
     double sd = sigma * sigma - (double)(SIFT_INIT_SIGMA * 2) * (SIFT_INIT_SIGMA * 2);
     sd = sqrt(sd > 0.01 ? sd : 0.01);
-    for (int o = 0; o < O.n_oct; ++o) {
+    // the octaves from `tail` on are small enough for one workgroup (sift_tail_octaves_kernel)
+    SiftTail T;
+    T.K[0].n = 0;
+    T.halo = 0;
+    for (int i = 1; i < layers + 3; ++i) {
+        if ((rc = sift_gauss_kernel(sig[i], T.K[i]))) return rc;
+        T.halo = T.K[i].n / 2 > T.halo ? T.K[i].n / 2 : T.halo;
+    }
+    int tail = O.n_oct;
+    while (tail > 1 && (size_t)O.w[tail - 1] * O.h[tail - 1] <= SIFT_TAIL_PIXELS &&
+           (size_t)(O.w[tail - 1] + 2 * T.halo) * O.h[tail - 1] <= SIFT_TAIL_PADDED &&
+           (size_t)O.w[tail - 1] * (O.h[tail - 1] + 2 * T.halo) <= SIFT_TAIL_PADDED)
+        --tail;
+    for (int o = 0; o < tail; ++o) {
         const int ow = O.w[o], oh = O.h[o];
         const size_t plane = (size_t)ow * oh;
         float *g = S.pool + O.gauss_off[o];
@@ -667,6 +759,10 @@ static int sift_build(vo_ctx *ctx, const uint8_t *d_img, int height, int width, 
         }
         hipLaunchKernelGGL(sift_dog_kernel, dim3((unsigned)((plane + 255) / 256), layers + 2), dim3(256), 0, ctx->stream, (const float *)g,
                            S.pool + O.dog_off[o], plane);
+    }
+    if (tail < O.n_oct) {
+        T.first = tail;
+        hipLaunchKernelGGL(sift_tail_octaves_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.pool, O, T);
     }
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
