@@ -51,6 +51,7 @@ struct SiftOctaves {
     int n_oct, layers;
     int w[SIFT_MAX_OCTAVES], h[SIFT_MAX_OCTAVES];
     size_t gauss_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];   // float offsets into the pool
+    int rmax[SIFT_MAX_OCTAVES];                                      // (int)sqrt(w^2 + h^2): cap of a descriptor window's radius
 };
 // descriptor job of one keypoint: image, rounded centre, rotation already divided by the histogram width
 struct SiftJob { int octave, layer, px, py, radius, out; float ori, cos_t, sin_t; };     // out: descriptor row
@@ -348,11 +349,54 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(const float *__restri
 
 // The keypoint lists put end to end: block b copies list b behind the lists before it; total[0] = the number of
 // keypoints, or cap + 1 when a list overflowed.
+#define SIFT_JOB_BINS 1024
+__device__ static inline int sift_job_bin(int radius) { return radius < SIFT_JOB_BINS - 1 ? radius : SIFT_JOB_BINS - 1; }
+
+// Descriptor job of raw keypoint k (coordinates of the doubled image, octave index from 0), in the float operations
+// OpenCV's calcSIFTDescriptor set-up applies to the keypoint it is handed (coordinates and size halved and the
+// octave shifted by -1 first, as the detector's last step does).
+__device__ static inline SiftJob sift_make_job(const vo_sift_keypoint &k, int row, const SiftOctaves &O)
+{
+    constexpr int d = SIFT_DESCR_WIDTH;
+    const int first_octave = -1;
+    const int shifted = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+    const float kx = k.x * 0.5f, ky = k.y * 0.5f, ksize = k.size * 0.5f;
+    int octave = shifted & 255;
+    const int layer = (shifted >> 8) & 255;
+    octave = octave < 128 ? octave : (-128 | octave);
+    const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+    const float size = ksize * scale, scl = size * 0.5f;
+    const float ptx = kx * scale, pty = ky * scale;
+    float angle = 360.f - k.angle;
+    if (fabsf(angle - 360.f) < SIFT_FLT_EPSILON) angle = 0.f;
+    SiftJob jb;
+    jb.octave = octave - first_octave;
+    jb.out = row;
+    jb.layer = layer;
+    jb.px = (int)rint((double)ptx);
+    jb.py = (int)rint((double)pty);
+    jb.ori = angle;
+    float cos_t, sin_t;
+    sift_sincos(angle * (float)(3.14159265358979323846 / 180.), &cos_t, &sin_t);
+    const float hist_width = SIFT_DESCR_SCL_FCTR * scl;
+    const int radius = (int)rint((double)(hist_width * 1.4142135623730951f * (d + 1) * 0.5f));
+    const int rmax = O.rmax[jb.octave];
+    jb.radius = radius < rmax ? radius : rmax;
+    jb.cos_t = cos_t / hist_width;
+    jb.sin_t = sin_t / hist_width;
+    return jb;
+}
+
+// Puts the keypoint lists end to end (workgroup b copies list b) and, with `unordered` given, forms every
+// keypoint's descriptor job on the way and counts the jobs per window radius (sift_order_jobs_kernel sorts by it).
 __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keypoint *__restrict__ lists, const int *__restrict__ counts,
-                                                             int cap, vo_sift_keypoint *__restrict__ joined, int *__restrict__ total)
+                                                             int cap, vo_sift_keypoint *__restrict__ joined, int *__restrict__ total,
+                                                             SiftOctaves O, SiftJob *__restrict__ unordered, int *__restrict__ radius_hist)
 {
     __shared__ int s_off, s_n;
+    __shared__ int hist[SIFT_JOB_BINS];
     const int list_cap = cap / SIFT_LISTS;
+    for (int b = threadIdx.x; b < SIFT_JOB_BINS; b += 256) hist[b] = 0;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x, raw = counts[lane * SIFT_LIST_STRIDE], mine = min(raw, list_cap);
         int upto = mine;
@@ -365,11 +409,20 @@ __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keyp
         if (blockIdx.x == 0 && lane == 63) total[0] = over ? cap + 1 : upto;
     }
     __syncthreads();
-    const uint2 *src = (const uint2 *)(lists + (size_t)blockIdx.x * list_cap);
-    uint2 *dst = (uint2 *)(joined + s_off);
-    static_assert(sizeof(vo_sift_keypoint) % 8 == 0, "keypoints are copied 8 bytes at a time");
-    const int words = s_n * (int)(sizeof(vo_sift_keypoint) / 8);
-    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+    const vo_sift_keypoint *src = lists + (size_t)blockIdx.x * list_cap;
+    for (int i = threadIdx.x; i < s_n; i += 256) {
+        const vo_sift_keypoint k = src[i];
+        joined[s_off + i] = k;
+        if (unordered) {
+            const SiftJob jb = sift_make_job(k, s_off + i, O);
+            unordered[s_off + i] = jb;
+            atomicAdd(&hist[sift_job_bin(jb.radius)], 1);
+        }
+    }
+    if (!unordered) return;
+    __syncthreads();
+    for (int b = threadIdx.x; b < SIFT_JOB_BINS; b += 256)
+        if (hist[b]) atomicAdd(&radius_hist[b], hist[b]);
 }
 
 // One wavefront per candidate.
@@ -659,6 +712,44 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     }
 }
 
+// The jobs ordered by window radius, largest first: a wavefront of the descriptor kernel serves four keypoints and
+// lasts as long as the largest of their windows.  One workgroup: scan of the radius counts, scatter (the order
+// inside a radius is whatever the atomics give; a job names its output row, so the descriptors do not depend on it).
+__global__ __launch_bounds__(1024) void sift_order_jobs_kernel(const SiftJob *__restrict__ unordered, int n, const int *__restrict__ radius_hist,
+                                                              SiftJob *__restrict__ jobs)
+{
+    __shared__ int start[SIFT_JOB_BINS];
+    __shared__ int wave_sum[16];
+    const int tid = threadIdx.x;
+    // exclusive scan over the bins from the largest radius down: thread t holds bin SIFT_JOB_BINS - 1 - t
+    const int mine = radius_hist[SIFT_JOB_BINS - 1 - tid];
+    int incl = mine;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int up = __shfl_up(incl, sft);
+        if ((tid & 63) >= sft) incl += up;
+    }
+    if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) before += wave_sum[wv];
+    start[SIFT_JOB_BINS - 1 - tid] = before + incl - mine;
+    __syncthreads();
+    for (int j = tid; j < n; j += 1024) {
+        const SiftJob jb = unordered[j];
+        jobs[atomicAdd(&start[sift_job_bin(jb.radius)], 1)] = jb;
+    }
+}
+
+// dst row i = src row rows[i] (128 floats each): the descriptors of the keypoints that survive the ordering, in its order
+__global__ __launch_bounds__(256) void sift_gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ rows, int n,
+                                                              float *__restrict__ dst)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = t >> 7;
+    if (row < (size_t)n) dst[t] = src[(size_t)rows[row] * 128 + (t & 127)];
+}
+
 // ---------------------------------------------------------------------------------------------------
 static int sift_gauss_kernel(double sigma, SiftKernel &K)
 {
@@ -714,6 +805,7 @@ static int sift_build(vo_ctx *ctx, const uint8_t *d_img, int height, int width, 
         O.h[o] = o == 0 ? H : O.h[o - 1] / 2;
         VO_REQUIRE(O.w[o] >= 1 && O.h[o] >= 1, "SIFT: octave %d of a %d x %d image is empty", o, width, height);
         const size_t plane = (size_t)O.w[o] * O.h[o];
+        O.rmax[o] = (int)sqrt((double)O.w[o] * O.w[o] + (double)O.h[o] * O.h[o]);
         O.gauss_off[o] = total; total += plane * (layers + 3);
         O.dog_off[o] = total; total += plane * (layers + 2);
     }
@@ -840,11 +932,20 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     // candidates and raw keypoints: counters | candidates | keypoints (context slot 3)
     // counters (candidate lists | keypoint lists | keypoint total) | candidates | keypoint lists | keypoints joined
     const int cand_cap = 1 << 19, kp_cap = 1 << 18;
-    const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64) * 4;
+    const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64 + SIFT_JOB_BINS) * 4;
     void *p;
     if ((rc = vo_stage_reserve(ctx, 3, cnt_bytes + (size_t)cand_cap * sizeof(SiftCand) + 2 * (size_t)kp_cap * sizeof(vo_sift_keypoint), &p)))
         return rc;
     int *d_cnt = (int *)p, *d_kcnt = d_cnt + SIFT_LISTS * SIFT_LIST_STRIDE, *d_ktotal = d_kcnt + SIFT_LISTS * SIFT_LIST_STRIDE;
+    int *d_radius_hist = d_ktotal + 64;
+    // descriptor jobs, unordered and ordered, for as many keypoints as the keypoint buffer holds (formed while the lists are joined)
+    const bool describe = descriptors && max_keypoints > 0;
+    SiftJob *d_jobs = nullptr;
+    if (describe) {
+        void *q;
+        if ((rc = vo_stage_reserve(ctx, 4, 2 * (size_t)kp_cap * sizeof(SiftJob), &q))) return rc;
+        d_jobs = (SiftJob *)q;
+    }
     SiftCand *d_cand = (SiftCand *)((char *)p + cnt_bytes);
     vo_sift_keypoint *d_klists = (vo_sift_keypoint *)((char *)p + cnt_bytes + (size_t)cand_cap * sizeof(SiftCand));
     vo_sift_keypoint *d_kp = d_klists + kp_cap;
@@ -877,25 +978,55 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
                            (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_klists, d_kcnt, kp_cap);
         hipLaunchKernelGGL(sift_join_lists_kernel, dim3(SIFT_LISTS), dim3(256), 0, ctx->stream, (const vo_sift_keypoint *)d_klists,
-                           (const int *)d_kcnt, kp_cap, d_kp, d_ktotal);
+                           (const int *)d_kcnt, kp_cap, d_kp, d_ktotal, O, describe ? d_jobs + kp_cap : (SiftJob *)nullptr, d_radius_hist);
         VO_HIP_CHECK(hipGetLastError());
     }
     VO_RESULT(ctx, h_cnt + 1, d_ktotal, 4);
     VO_RESULTS_FINISH(ctx);
     if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
-    std::vector<vo_sift_keypoint> kps((size_t)h_cnt[1]);
-    if (h_cnt[1]) {
-        void *pin;      // through page-locked memory: a copy into pageable memory is staged in small pieces
-        if ((rc = vo_pinned_reserve(ctx, kps.size() * sizeof(vo_sift_keypoint), &pin))) return rc;
-        if ((rc = vo_download_async(ctx, pin, d_kp, kps.size() * sizeof(vo_sift_keypoint)))) return rc;
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        memcpy(kps.data(), pin, kps.size() * sizeof(vo_sift_keypoint));
+    const size_t n_raw = (size_t)h_cnt[1];
+    if (n_raw == 0) { *n_keypoints = 0; return VO_OK; }
+    // Everything the rest of the call needs, before anything is queued (growing a buffer waits for the device):
+    // page-locked room for the keypoints coming back and the row order going out; the jobs, the descriptors of all
+    // raw keypoints, the row order and -- for a host caller -- the ordered descriptors on the device.
+    const size_t kp_bytes = (n_raw * sizeof(vo_sift_keypoint) + 15) & ~(size_t)15, row_bytes = (n_raw * 4 + 15) & ~(size_t)15;
+    void *pin;
+    if ((rc = vo_pinned_reserve(ctx, kp_bytes + row_bytes, &pin))) return rc;
+    const vo_sift_keypoint *h_raw = (const vo_sift_keypoint *)pin;
+    int *h_rows = (int *)((char *)pin + kp_bytes);
+    float *d_raw_desc = nullptr, *d_desc = descriptors;
+    int *d_rows = nullptr;
+    if (describe) {
+        if ((rc = vo_stage_reserve(ctx, 6, n_raw * 128 * 4, &p))) return rc;
+        d_raw_desc = (float *)p;
+        if ((rc = vo_stage_reserve(ctx, 7, row_bytes, &p))) return rc;
+        d_rows = (int *)p;
+        if (mem == VO_MEM_HOST) {
+            const size_t most = n_raw < (size_t)max_keypoints ? n_raw : (size_t)max_keypoints;
+            if ((rc = vo_stage_reserve(ctx, 5, most * 128 * 4, &p))) return rc;
+            d_desc = (float *)p;
+        }
     }
+    // The keypoints leave for the host first; the descriptors of ALL raw keypoints are computed while the host puts
+    // them in order (a descriptor does not depend on the keypoint's place in the output, only its row does, and the
+    // few duplicates the ordering drops cost less than the device idling through it).
+    if ((rc = vo_download_async(ctx, pin, d_kp, n_raw * sizeof(vo_sift_keypoint)))) return rc;
+    VO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (describe) {
+        hipLaunchKernelGGL(sift_order_jobs_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const SiftJob *)(d_jobs + kp_cap), (int)n_raw,
+                           (const int *)d_radius_hist, d_jobs);
+        hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)((n_raw + 3) / 4)), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
+                           (const SiftJob *)d_jobs, (int)n_raw, d_raw_desc);
+        VO_HIP_CHECK(hipGetLastError());
+    }
+    VO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    struct Rec { vo_sift_keypoint k; uint32_t row; };      // a raw keypoint and where it (and its descriptor) stands in the raw list
+    std::vector<Rec> kps(n_raw);
+    for (size_t i = 0; i < n_raw; ++i) { kps[i].k = h_raw[i]; kps[i].row = (uint32_t)i; }
     // KeyPointsFilter::removeDuplicatedSorted: order by (x, y, size desc, angle, response desc, octave desc), drop repeats.
-    // Coordinates are non-negative floats, whose bit patterns order like the values: one 64-bit key sorts by (x, y);
-    // runs of equal keys (a keypoint with several orientations) are then put in the full order.
     {
-        const auto full_less = [](const vo_sift_keypoint &a, const vo_sift_keypoint &b) {
+        const auto full_less = [](const Rec &ra, const Rec &rb) {
+            const vo_sift_keypoint &a = ra.k, &b = rb.k;
             if (a.x != b.x) return a.x < b.x;
             if (a.y != b.y) return a.y < b.y;
             if (a.size != b.size) return a.size > b.size;
@@ -908,15 +1039,15 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         // comparison sort over tens of thousands of records)
         const int nbuckets = 2 * width + 2;
         bool plain = true;
-        for (const auto &k : kps) plain = plain && k.x >= 0 && k.x < (float)(nbuckets - 1);   // always true for SIFT; else: full sort
+        for (const auto &r : kps) plain = plain && r.k.x >= 0 && r.k.x < (float)(nbuckets - 1);   // always true for SIFT; else: full sort
         if (plain && kps.size() > 64) {
             std::vector<uint32_t> start((size_t)nbuckets + 1, 0);
-            for (const auto &k : kps) ++start[(size_t)(int)k.x + 1];
+            for (const auto &r : kps) ++start[(size_t)(int)r.k.x + 1];
             for (int b = 0; b < nbuckets; ++b) start[(size_t)b + 1] += start[b];
-            std::vector<vo_sift_keypoint> sorted(kps.size());
+            std::vector<Rec> sorted(kps.size());
             {
                 std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-                for (const auto &k : kps) sorted[fill[(size_t)(int)k.x]++] = k;
+                for (const auto &r : kps) sorted[fill[(size_t)(int)r.k.x]++] = r;
             }
             for (int b = 0; b < nbuckets; ++b)
                 if (start[(size_t)b + 1] - start[b] > 1) std::sort(sorted.begin() + start[b], sorted.begin() + start[(size_t)b + 1], full_less);
@@ -927,80 +1058,29 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     }
     size_t m = 0;
     for (size_t i = 0; i < kps.size(); ++i) {
-        if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle)
+        if (m > 0 && kps[i].k.x == kps[m - 1].k.x && kps[i].k.y == kps[m - 1].k.y && kps[i].k.size == kps[m - 1].k.size &&
+            kps[i].k.angle == kps[m - 1].k.angle)
             continue;
         kps[m++] = kps[i];
     }
-    kps.resize(m);
-    const int first_octave = -1;
-    for (auto &k : kps) {       // back to the coordinates of the input image (the scale space starts at the doubled image)
-        k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
-        k.x *= 0.5f; k.y *= 0.5f; k.size *= 0.5f;
-    }
     *n_keypoints = (int32_t)m;
     const size_t n_out = m < (size_t)max_keypoints ? m : (size_t)max_keypoints;
-    for (size_t i = 0; i < n_out; ++i) keypoints[i] = kps[i];
-    if (!descriptors || n_out == 0) return VO_OK;
-
-    std::vector<SiftJob> jobs(n_out);
-    constexpr int d = SIFT_DESCR_WIDTH;
-    for (size_t i = 0; i < n_out; ++i) {
-        int octave = kps[i].octave & 255;
-        const int layer = (kps[i].octave >> 8) & 255;
-        octave = octave < 128 ? octave : (-128 | octave);
-        const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
-        const float size = kps[i].size * scale, scl = size * 0.5f;
-        const float ptx = kps[i].x * scale, pty = kps[i].y * scale;
-        float angle = 360.f - kps[i].angle;
-        if (fabsf(angle - 360.f) < SIFT_FLT_EPSILON) angle = 0.f;
-        SiftJob &jb = jobs[i];
-        jb.octave = octave - first_octave;
-        jb.out = (int)i;
-        jb.layer = layer;
-        jb.px = (int)lrint((double)ptx);
-        jb.py = (int)lrint((double)pty);
-        jb.ori = angle;
-        float cos_t, sin_t;
-        sift_sincos(angle * (float)(3.14159265358979323846 / 180.), &cos_t, &sin_t);
-        const float hist_width = SIFT_DESCR_SCL_FCTR * scl;
-        int radius = (int)lrint((double)(hist_width * 1.4142135623730951f * (d + 1) * 0.5f));
-        const int w = O.w[jb.octave], h = O.h[jb.octave];
-        const int rmax = (int)sqrt((double)w * w + (double)h * h);
-        jb.radius = radius < rmax ? radius : rmax;
-        jb.cos_t = cos_t / hist_width;
-        jb.sin_t = sin_t / hist_width;
+    const int first_octave = -1;
+    for (size_t i = 0; i < n_out; ++i) {       // back to the coordinates of the input image (the scale space starts at the doubled image)
+        vo_sift_keypoint k = kps[i].k;
+        k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+        k.x *= 0.5f; k.y *= 0.5f; k.size *= 0.5f;
+        keypoints[i] = k;
+        h_rows[i] = (int)kps[i].row;
     }
-    // a wavefront serves four keypoints and lasts as long as the largest of their windows: neighbours of equal size
-    // (stable counting sort on the radius, largest first)
-    {
-        int rtop = 0;
-        for (const auto &jb : jobs) rtop = jb.radius > rtop ? jb.radius : rtop;
-        std::vector<uint32_t> start((size_t)rtop + 2, 0);
-        for (const auto &jb : jobs) ++start[(size_t)(rtop - jb.radius) + 1];
-        for (int r = 0; r <= rtop; ++r) start[(size_t)r + 1] += start[r];
-        std::vector<SiftJob> by_radius(jobs.size());
-        for (const auto &jb : jobs) by_radius[start[(size_t)(rtop - jb.radius)]++] = jb;
-        jobs.swap(by_radius);
-    }
-    if ((rc = vo_stage_reserve(ctx, 4, n_out * sizeof(SiftJob), &p))) return rc;
-    SiftJob *d_jobs = (SiftJob *)p;
-    float *d_desc = descriptors;
-    if (mem == VO_MEM_HOST) {
-        if ((rc = vo_stage_reserve(ctx, 5, n_out * 128 * 4, &p))) return rc;
-        d_desc = (float *)p;
-    }
-    {
-        void *pin;
-        if ((rc = vo_pinned_reserve(ctx, n_out * sizeof(SiftJob), &pin))) return rc;
-        memcpy(pin, jobs.data(), n_out * sizeof(SiftJob));
-        if ((rc = vo_copy_pinned_wide_async(ctx, d_jobs, pin, n_out * sizeof(SiftJob)))) return rc;
-    }
-    hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
-                       (const SiftJob *)d_jobs, (int)n_out, d_desc);
+    if (!describe) return VO_OK;
+    if ((rc = vo_copy_pinned_wide_async(ctx, d_rows, h_rows, n_out * 4))) return rc;
+    hipLaunchKernelGGL(sift_gather_rows_kernel, dim3((unsigned)((n_out * 128 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float *)d_raw_desc, (const int *)d_rows, (int)n_out, d_desc);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST)
         VO_HIP_CHECK(hipMemcpyAsync(descriptors, d_desc, n_out * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    // the page-locked job list must stay untouched until the kernel has read its copy: wait in both memory modes
+    // the page-locked row order must stay untouched until the kernel has read its copy: wait in both memory modes
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
