@@ -22,7 +22,12 @@
 //                            a time, compacted in raster order; lane c owns inner cell c of the histogram (only the
 //                            4x4 inner cells of the 6x6x10 histogram reach the descriptor) and adds the samples that
 //                            touch it in that order
-// Sorting / de-duplication of the few thousand keypoints runs on the host between the two per-keypoint kernels.
+//   sift_tail_octaves_kernel the small octaves at the end of the scale space, all layers, in one launch
+//   sift_join_lists_kernel   keypoint lists end to end; forms every keypoint's descriptor job on the way
+//   sift_order_jobs_kernel   jobs by window radius, largest first
+//   sift_gather_rows_kernel  descriptor rows of the surviving keypoints in output order
+// Sorting / de-duplication of the keypoints runs on the host while the device computes the descriptors of all raw
+// keypoints; the rows of the survivors are gathered afterwards.
 #include "vo_internal.h"
 #include <math.h>
 #include <algorithm>
@@ -987,8 +992,8 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     const size_t n_raw = (size_t)h_cnt[1];
     if (n_raw == 0) { *n_keypoints = 0; return VO_OK; }
     // Everything the rest of the call needs, before anything is queued (growing a buffer waits for the device):
-    // page-locked room for the keypoints coming back and the row order going out; the jobs, the descriptors of all
-    // raw keypoints, the row order and -- for a host caller -- the ordered descriptors on the device.
+    // page-locked room for the keypoints coming back and the row order going out; the descriptors of all raw
+    // keypoints, the row order and -- for a host caller -- the ordered descriptors on the device.
     const size_t kp_bytes = (n_raw * sizeof(vo_sift_keypoint) + 15) & ~(size_t)15, row_bytes = (n_raw * 4 + 15) & ~(size_t)15;
     void *pin;
     if ((rc = vo_pinned_reserve(ctx, kp_bytes + row_bytes, &pin))) return rc;
