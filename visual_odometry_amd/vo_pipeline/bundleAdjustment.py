@@ -7,7 +7,9 @@ frozen, cost 0.5*|r|^2, ftol 1e-4 -- but where the reference hands scipy's TRF a
 finite-difference Jacobian, this runs Levenberg-Marquardt on the analytic normal
 equations with a Schur complement on the landmarks, all on the GPU (vo_ba_create /
 vo_ba_try_step / vo_ba_accept).  Iterates therefore differ from scipy's; the
-residual, cost and Jacobian at a given x are the same.
+residual, cost and Jacobian at a given x are the same.  A window ends when an accepted
+step gains less than ftol of the cost, when a rejected step moved it by less than that
+(stronger damping could only gain less), or after ten rejected steps in a row.
 """
 from typing import Tuple
 
@@ -144,18 +146,26 @@ class BundleAdjustment:
             cost = solver.linearize(x)
             lam = 1e-3
             for _ in range(max_iters):
-                improved = False
+                improved = converged = False
                 prev = cost
                 for _try in range(10):
                     cost_new, solved = solver.try_step(lam)
-                    if solved and np.isfinite(cost_new) and cost_new < cost:
+                    usable = solved and np.isfinite(cost_new)
+                    if usable and cost_new < cost:
                         solver.accept()
                         cost = cost_new
                         lam = max(lam / 3, 1e-9)
                         improved = True
                         break
+                    # A rejected step that moves the cost by less than the tolerance: stronger damping only shortens
+                    # the step along (nearly) the same direction, so nothing above the tolerance is left to gain.
+                    # (The frozen cameras' observations count in the cost but not in the Jacobian -- the reference's
+                    # sparsity pattern --, so the model's minimum is not exactly the cost's and such endings are common.)
+                    if usable and abs(cost_new - cost) < ftol * cost:
+                        converged = True
+                        break
                     lam *= 10
-                if not improved or (prev - cost) < ftol * prev:
+                if converged or not improved or (prev - cost) < ftol * prev:
                     break
             return solver.params()
         finally:
