@@ -2405,8 +2405,10 @@ extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem,
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_linearize: bad mem flag %d", mem);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
-    VO_HIP_CHECK(hipMemcpyAsync(ba->x[ba->cur], x, np_ * 8, mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                                ctx->stream));
+    // a host vector goes through the context's page-locked ring (a copy from pageable memory blocks, and the first one
+    // of a process sets up the runtime's own staging: 5 ms)
+    if (mem == VO_MEM_HOST) VO_UPLOAD(ctx, ba->x[ba->cur], x, np_ * 8);
+    else VO_HIP_CHECK(hipMemcpyAsync(ba->x[ba->cur], x, np_ * 8, hipMemcpyDeviceToDevice, ctx->stream));
     int rc = ba_linearize_into(ba, ba->cur);
     if (rc) return rc;
     VO_RESULT(ctx, cost, ba->cost[ba->cur], 8);
@@ -2508,8 +2510,11 @@ extern "C" int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, in
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
     const int slot = candidate ? 1 - ba->cur : ba->cur;
-    VO_HIP_CHECK(hipMemcpyAsync(x, ba->x[slot], np_ * 8, mem == VO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                                ctx->stream));
-    if (mem == VO_MEM_HOST) VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mem == VO_MEM_HOST) {
+        VO_RESULT(ctx, x, ba->x[slot], np_ * 8);
+        VO_RESULTS_FINISH(ctx);
+    } else {
+        VO_HIP_CHECK(hipMemcpyAsync(x, ba->x[slot], np_ * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     return VO_OK;
 }
