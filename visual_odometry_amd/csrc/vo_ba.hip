@@ -536,15 +536,16 @@ static int ba_common(vo_ctx *ctx, const double *params, int F, int P, const int6
     }
     }
     if (mem == VO_MEM_HOST) {
-        if (O) VO_HIP_CHECK(hipMemcpyAsync(r, d_r, (size_t)O * 16, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(cost, d_cost, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // through the context's page-locked result area where they fit (vo_result), one wait for all of them
+        if (O) VO_RESULT(ctx, r, d_r, (size_t)O * 16);
+        VO_RESULT(ctx, cost, d_cost, 8);
         if (WITH_J) {
-            if (F) VO_HIP_CHECK(hipMemcpyAsync(Hcc, d_Hcc, (size_t)F * 288, hipMemcpyDeviceToHost, ctx->stream));
-            if (P) VO_HIP_CHECK(hipMemcpyAsync(Hpp, d_Hpp, (size_t)P * 72, hipMemcpyDeviceToHost, ctx->stream));
-            if (np_) VO_HIP_CHECK(hipMemcpyAsync(g, d_g, np_ * 8, hipMemcpyDeviceToHost, ctx->stream));
-            if (O) VO_HIP_CHECK(hipMemcpyAsync(Hcp, d_Hcp, (size_t)O * 144, hipMemcpyDeviceToHost, ctx->stream));
+            if (F) VO_RESULT(ctx, Hcc, d_Hcc, (size_t)F * 288);
+            if (P) VO_RESULT(ctx, Hpp, d_Hpp, (size_t)P * 72);
+            if (np_) VO_RESULT(ctx, g, d_g, np_ * 8);
+            if (O) VO_RESULT(ctx, Hcp, d_Hcp, (size_t)O * 144);
         }
-        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        VO_RESULTS_FINISH(ctx);
     }
     return VO_OK;
 }
