@@ -3,6 +3,7 @@
 frames/s of the whole loop (host numpy in and out of every operator, as the reference calls
 them) and the error of the recovered trajectory against the scene's ground truth."""
 import argparse
+import gc
 import json
 import logging
 import os
@@ -199,6 +200,11 @@ def main():
         timed(_hip.BaSolver, "close", "BaSolver.close")
         timed(bam.BundleAdjustment, "_preprocess_data", "BA._preprocess_data")
         timed(bam.BundleAdjustment, "_camera_params", "BA._camera_params", static=True)
+    # everything imported and built so far (torch, scipy, the synthetic sequence) into the collector's permanent
+    # generation: a full collection inside the loop then walks the loop's own objects, not a million module-level
+    # ones (such a pause is 5-10 ms, a tracked frame 0.3 ms)
+    gc.collect()
+    gc.freeze()
     per_frame = []
     while True:
         t0 = time.perf_counter()
