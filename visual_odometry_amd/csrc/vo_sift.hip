@@ -12,9 +12,9 @@
 // Kernels (all HBM/L2-bound float32 streaming or small per-keypoint work; no contraction that would suit MFMA):
 //   sift_upsample_kernel     u8 -> float32, 2x bilinear
 //   sift_blur_rows/cols      separable Gaussian, REFLECT_101; rows add their taps left to right, columns in
-//                            symmetric pairs (the order of OpenCV's float row and column filters)
+//                            symmetric pairs (the order of OpenCV's float row and column filters); the column
+//                            pass also writes the difference from the layer below
 //   sift_halve_kernel        next octave's base = every second pixel
-//   sift_dog_kernel          all differences of an octave in one launch
 //   sift_extrema_kernel      26-neighbour test over the four middle layers; candidates appended with one atomic
 //   sift_refine_kernel       one wavefront per candidate: Newton refinement (every lane, same values), orientation
 //                            histogram with lane b adding bin b's samples in raster order (deterministic float sums)
@@ -24,7 +24,7 @@
 //                            touch it in that order
 //   sift_tail_octaves_kernel the small octaves at the end of the scale space, all layers, in one launch
 //   sift_join_lists_kernel   keypoint lists end to end; forms every keypoint's descriptor job on the way
-//   sift_order_jobs_kernel   jobs by window radius, largest first
+//   sift_order_jobs_kernel   jobs by window radius, largest first (workgroup b places list b)
 //   sift_gather_rows_kernel  descriptor rows of the surviving keypoints in output order
 // Sorting / de-duplication of the keypoints runs on the host while the device computes the descriptors of all raw
 // keypoints; the rows of the survivors are gathered afterwards.
@@ -176,10 +176,11 @@ __global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float *__rest
 // Column pass: a workgroup stages a 64-column strip of SIFT_COL_ROWS + 2r rows in LDS (rows reflected at the image
 // border; 64 consecutive floats per row, so global reads are coalesced and LDS reads conflict-free), then every
 // lane finishes eight outputs of its column from LDS: centre tap first, then symmetric pairs.  Every input row
-// is read from memory (SIFT_COL_ROWS + 2r) / SIFT_COL_ROWS times instead of 2r + 1 times.
+// is read from memory (SIFT_COL_ROWS + 2r) / SIFT_COL_ROWS times instead of 2r + 1 times.  With `diff` given the
+// difference from the layer below (the image the row pass read) is written on the way.
 #define SIFT_COL_ROWS 32
 __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-                                                            SiftKernel K)
+                                                            SiftKernel K, const float *__restrict__ below, float *__restrict__ diff)
 {
     __shared__ float tile[(SIFT_COL_ROWS + SIFT_MAX_TAPS + 1) * 64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -193,7 +194,9 @@ __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__rest
         const float *c = tile + (yy + r) * 64 + tx;
         float acc = K.k[r] * c[0];
         for (int j = 1; j <= r; ++j) acc += K.k[r + j] * (c[j * 64] + c[-j * 64]);
-        dst[(size_t)(y0 + yy) * w + x] = acc;
+        const size_t at = (size_t)(y0 + yy) * w + x;
+        dst[at] = acc;
+        if (diff) diff[at] = acc - below[at];        // difference of Gaussians: this layer minus the one it was blurred from
     }
 }
 
@@ -201,15 +204,6 @@ __global__ __launch_bounds__(256) void sift_halve_kernel(const float *__restrict
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < w && y < h) dst[(size_t)y * w + x] = src[(size_t)(2 * y) * sw + 2 * x];
-}
-
-// dog[i] = gauss[i + 1] - gauss[i] for i = blockIdx.y; images of one octave are `plane` floats apart
-__global__ __launch_bounds__(256) void sift_dog_kernel(const float *__restrict__ gauss, float *__restrict__ dog, size_t plane)
-{
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= plane) return;
-    const float *a = gauss + plane * blockIdx.y;
-    dog[plane * blockIdx.y + t] = a[plane + t] - a[t];
 }
 
 // The small octaves at the end of the scale space (a 1241 x 376 frame: 77 x 23 pixels and down) in one launch: a
@@ -393,7 +387,8 @@ __device__ static inline SiftJob sift_make_job(const vo_sift_keypoint &k, int ro
 }
 
 // Puts the keypoint lists end to end (workgroup b copies list b) and, with `unordered` given, forms every
-// keypoint's descriptor job on the way and counts the jobs per window radius (sift_order_jobs_kernel sorts by it).
+// keypoint's descriptor job on the way and counts its list's jobs per window radius (row b of radius_hist;
+// sift_order_jobs_kernel sorts by it).
 __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keypoint *__restrict__ lists, const int *__restrict__ counts,
                                                              int cap, vo_sift_keypoint *__restrict__ joined, int *__restrict__ total,
                                                              SiftOctaves O, SiftJob *__restrict__ unordered, int *__restrict__ radius_hist)
@@ -426,8 +421,7 @@ __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keyp
     }
     if (!unordered) return;
     __syncthreads();
-    for (int b = threadIdx.x; b < SIFT_JOB_BINS; b += 256)
-        if (hist[b]) atomicAdd(&radius_hist[b], hist[b]);
+    for (int b = threadIdx.x; b < SIFT_JOB_BINS; b += 256) radius_hist[blockIdx.x * SIFT_JOB_BINS + b] = hist[b];
 }
 
 // One wavefront per candidate.
@@ -718,17 +712,39 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
 }
 
 // The jobs ordered by window radius, largest first: a wavefront of the descriptor kernel serves four keypoints and
-// lasts as long as the largest of their windows.  One workgroup: scan of the radius counts, scatter (the order
-// inside a radius is whatever the atomics give; a job names its output row, so the descriptors do not depend on it).
-__global__ __launch_bounds__(1024) void sift_order_jobs_kernel(const SiftJob *__restrict__ unordered, int n, const int *__restrict__ radius_hist,
-                                                              SiftJob *__restrict__ jobs)
+// lasts as long as the largest of their windows.  Workgroup b places the jobs of list b: from the per-list radius
+// counts every workgroup works out where each radius starts (scan over the totals, largest radius first) and how
+// many jobs of that radius the lists before its own hold; inside one list and radius the order is whatever the LDS
+// atomics give (a job names its output row, so the descriptors do not depend on it).
+__global__ __launch_bounds__(256) void sift_order_jobs_kernel(const SiftJob *__restrict__ unordered, const int *__restrict__ counts, int cap,
+                                                             const int *__restrict__ radius_hist, SiftJob *__restrict__ jobs)
 {
-    __shared__ int start[SIFT_JOB_BINS];
-    __shared__ int wave_sum[16];
-    const int tid = threadIdx.x;
-    // exclusive scan over the bins from the largest radius down: thread t holds bin SIFT_JOB_BINS - 1 - t
-    const int mine = radius_hist[SIFT_JOB_BINS - 1 - tid];
-    int incl = mine;
+    __shared__ int s_off, s_n;
+    __shared__ int base[SIFT_JOB_BINS];
+    __shared__ int wave_sum[4];
+    const int tid = threadIdx.x, list_cap = cap / SIFT_LISTS;
+    if (tid < 64) {
+        const int raw = counts[tid * SIFT_LIST_STRIDE], mine = min(raw, list_cap);
+        int upto = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(upto, d);
+            if (tid >= d) upto += o;
+        }
+        if (tid == (int)blockIdx.x) { s_off = upto - mine; s_n = mine; }
+    }
+    // thread t holds bins SIFT_JOB_BINS - 1 - 4t ... - 4t - 3 (descending radius): totals over the lists, and the lists before this one
+    int tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+    for (int l = 0; l < SIFT_LISTS; ++l) {
+        const int4 v = ((const int4 *)(radius_hist + l * SIFT_JOB_BINS))[255 - tid];
+        const int q[4] = {v.w, v.z, v.y, v.x};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tot[k] += q[k];
+            if (l < (int)blockIdx.x) pre[k] += q[k];
+        }
+    }
+    const int sum4 = tot[0] + tot[1] + tot[2] + tot[3];
+    int incl = sum4;
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) {
         const int up = __shfl_up(incl, sft);
@@ -736,13 +752,17 @@ __global__ __launch_bounds__(1024) void sift_order_jobs_kernel(const SiftJob *__
     }
     if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
     __syncthreads();
-    int before = 0;
-    for (int wv = 0; wv < (tid >> 6); ++wv) before += wave_sum[wv];
-    start[SIFT_JOB_BINS - 1 - tid] = before + incl - mine;
+    int start = incl - sum4;
+    for (int wv = 0; wv < (tid >> 6); ++wv) start += wave_sum[wv];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        base[SIFT_JOB_BINS - 1 - (4 * tid + k)] = start + pre[k];
+        start += tot[k];
+    }
     __syncthreads();
-    for (int j = tid; j < n; j += 1024) {
-        const SiftJob jb = unordered[j];
-        jobs[atomicAdd(&start[sift_job_bin(jb.radius)], 1)] = jb;
+    for (int i = tid; i < s_n; i += 256) {
+        const SiftJob jb = unordered[s_off + i];
+        jobs[atomicAdd(&base[sift_job_bin(jb.radius)], 1)] = jb;
     }
 }
 
@@ -773,14 +793,15 @@ static int sift_gauss_kernel(double sigma, SiftKernel &K)
     return VO_OK;
 }
 
-static int sift_blur(vo_ctx *ctx, const float *src, float *dst, float *tmp, int w, int h, double sigma)
+// dst = src blurred with sigma; with `diff` also diff = dst - src
+static int sift_blur(vo_ctx *ctx, const float *src, float *dst, float *tmp, int w, int h, double sigma, float *diff)
 {
     SiftKernel K;
     int rc = sift_gauss_kernel(sigma, K);
     if (rc) return rc;
     hipLaunchKernelGGL(sift_blur_rows_kernel, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, tmp, w, h, K);
     hipLaunchKernelGGL(sift_blur_cols_kernel, dim3((w + 63) / 64, (h + SIFT_COL_ROWS - 1) / SIFT_COL_ROWS), dim3(256), 0, ctx->stream,
-                       (const float *)tmp, dst, w, h, K);
+                       (const float *)tmp, dst, w, h, K, src, diff);
     return VO_OK;
 }
 
@@ -848,14 +869,12 @@ static int sift_build(vo_ctx *ctx, const uint8_t *d_img, int height, int width, 
         float *g = S.pool + O.gauss_off[o];
         for (int i = 0; i < layers + 3; ++i) {
             float *dst = g + plane * i;
-            if (o == 0 && i == 0) { if ((rc = sift_blur(ctx, dbl, dst, S.tmp, ow, oh, sd))) return rc; }
+            if (o == 0 && i == 0) { if ((rc = sift_blur(ctx, dbl, dst, S.tmp, ow, oh, sd, nullptr))) return rc; }
             else if (i == 0)
                 hipLaunchKernelGGL(sift_halve_kernel, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, ctx->stream,
                                    (const float *)(S.pool + O.gauss_off[o - 1] + (size_t)O.w[o - 1] * O.h[o - 1] * layers), O.w[o - 1], dst, ow, oh);
-            else if ((rc = sift_blur(ctx, dst - plane, dst, S.tmp, ow, oh, sig[i]))) return rc;
+            else if ((rc = sift_blur(ctx, dst - plane, dst, S.tmp, ow, oh, sig[i], S.pool + O.dog_off[o] + plane * (i - 1)))) return rc;
         }
-        hipLaunchKernelGGL(sift_dog_kernel, dim3((unsigned)((plane + 255) / 256), layers + 2), dim3(256), 0, ctx->stream, (const float *)g,
-                           S.pool + O.dog_off[o], plane);
     }
     if (tail < O.n_oct) {
         T.first = tail;
@@ -937,19 +956,21 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     // candidates and raw keypoints: counters | candidates | keypoints (context slot 3)
     // counters (candidate lists | keypoint lists | keypoint total) | candidates | keypoint lists | keypoints joined
     const int cand_cap = 1 << 19, kp_cap = 1 << 18;
-    const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64 + SIFT_JOB_BINS) * 4;
+    const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64) * 4;
     void *p;
     if ((rc = vo_stage_reserve(ctx, 3, cnt_bytes + (size_t)cand_cap * sizeof(SiftCand) + 2 * (size_t)kp_cap * sizeof(vo_sift_keypoint), &p)))
         return rc;
     int *d_cnt = (int *)p, *d_kcnt = d_cnt + SIFT_LISTS * SIFT_LIST_STRIDE, *d_ktotal = d_kcnt + SIFT_LISTS * SIFT_LIST_STRIDE;
-    int *d_radius_hist = d_ktotal + 64;
+    int *d_radius_hist = nullptr;       // SIFT_LISTS rows of SIFT_JOB_BINS counts behind the job arrays (rewritten whole by every call)
     // descriptor jobs, unordered and ordered, for as many keypoints as the keypoint buffer holds (formed while the lists are joined)
     const bool describe = descriptors && max_keypoints > 0;
     SiftJob *d_jobs = nullptr;
     if (describe) {
         void *q;
-        if ((rc = vo_stage_reserve(ctx, 4, 2 * (size_t)kp_cap * sizeof(SiftJob), &q))) return rc;
+        const size_t job_bytes = (2 * (size_t)kp_cap * sizeof(SiftJob) + 255) & ~(size_t)255;
+        if ((rc = vo_stage_reserve(ctx, 4, job_bytes + (size_t)SIFT_LISTS * SIFT_JOB_BINS * 4, &q))) return rc;
         d_jobs = (SiftJob *)q;
+        d_radius_hist = (int *)((char *)q + job_bytes);
     }
     SiftCand *d_cand = (SiftCand *)((char *)p + cnt_bytes);
     vo_sift_keypoint *d_klists = (vo_sift_keypoint *)((char *)p + cnt_bytes + (size_t)cand_cap * sizeof(SiftCand));
@@ -1018,8 +1039,8 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
     if ((rc = vo_download_async(ctx, pin, d_kp, n_raw * sizeof(vo_sift_keypoint)))) return rc;
     VO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
     if (describe) {
-        hipLaunchKernelGGL(sift_order_jobs_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const SiftJob *)(d_jobs + kp_cap), (int)n_raw,
-                           (const int *)d_radius_hist, d_jobs);
+        hipLaunchKernelGGL(sift_order_jobs_kernel, dim3(SIFT_LISTS), dim3(256), 0, ctx->stream, (const SiftJob *)(d_jobs + kp_cap),
+                           (const int *)d_kcnt, kp_cap, (const int *)d_radius_hist, d_jobs);
         hipLaunchKernelGGL(sift_descriptor_kernel, dim3((unsigned)((n_raw + 3) / 4)), dim3(64), 0, ctx->stream, (const float *)S.pool, O,
                            (const SiftJob *)d_jobs, (int)n_raw, d_raw_desc);
         VO_HIP_CHECK(hipGetLastError());
