@@ -175,10 +175,15 @@ __global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float *__rest
 
 // Column pass: a workgroup stages a 64-column strip of SIFT_COL_ROWS + 2r rows in LDS (rows reflected at the image
 // border; 64 consecutive floats per row, so global reads are coalesced and LDS reads conflict-free), then every
-// lane finishes eight outputs of its column from LDS: centre tap first, then symmetric pairs.  Every input row
-// is read from memory (SIFT_COL_ROWS + 2r) / SIFT_COL_ROWS times instead of 2r + 1 times.  With `diff` given the
-// difference from the layer below (the image the row pass read) is written on the way.
-#define SIFT_COL_ROWS 32
+// lane finishes SIFT_COL_ROWS / 4 outputs of its column from LDS: centre tap first, then symmetric pairs.  Every
+// input row is read (SIFT_COL_ROWS + 2r) / SIFT_COL_ROWS times -- from L2 after the first -- instead of 2r + 1
+// times.  Short strips win: the pass is bound by the latency of a workgroup's load-then-compute sequence, not by
+// bytes, and 8-row strips put four times the workgroups of 32-row ones in flight (whole SIFT call at 1241 x 376:
+// 1.73 / 1.53 / 1.43 / 1.40 ms with 64 / 32 / 16 / 8 rows).  With `diff` given the difference from the layer below
+// (the image the row pass read) is written on the way.
+#ifndef SIFT_COL_ROWS
+#define SIFT_COL_ROWS 8
+#endif
 __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                             SiftKernel K, const float *__restrict__ below, float *__restrict__ diff)
 {
