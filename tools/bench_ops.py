@@ -239,7 +239,6 @@ def main():
         ms_space = (time.perf_counter() - t0) / 10 * 1e3
         t0 = time.perf_counter(); oracle.sift(im); cpu = (time.perf_counter() - t0) * 1e3
         W2, H2 = 2 * shape[1], 2 * shape[0]
-        space_bytes = int(W2 * H2 * 4 * (4.0 / 3.0) * (7 * 3 + 6 * 3))     # per Gaussian image: row pass r+w, column pass r+w... (see DESIGN)
         out.append({"op": "sift_detect_compute", "workload": f"one {name} frame, nOctaveLayers 4, contrast 0.03, edge 10, sigma 1.6 "
                     f"({len(kp)} keypoints); device-resident image and descriptors; host wall time (keypoints are ordered on the host while the descriptors are computed)", "ms": ms,
                     "keypoints": int(len(kp)), "ms_scale_space_image_call (host image up, two builds, the finest 7.5 MB plane read back)": ms_space, "cpu_oracle_ms": cpu, "cpu_cores": 1})
