@@ -346,7 +346,7 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     double *dF = (double *)p;
     if ((rc = vo_stage_reserve(ctx, 5, (size_t)S * 16 + 16, &p))) return rc;
     int32_t *dcounts = (int32_t *)p, *dnsol = dcounts + 3 * (size_t)S;
-    if ((rc = vo_stage_reserve(ctx, 6, (size_t)n, &p))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 6, (size_t)n + 16, &p))) return rc;     // read back 16 bytes at a time
     uint8_t *dmask = (uint8_t *)p;
     memcpy(pin_m1, m1, (size_t)n * 8);
     memcpy(pin_m2, m2, (size_t)n * 8);
@@ -364,8 +364,10 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
         }
         if ((rc = vo_seven_point_solve(ctx, d1, d2, n, dsub + (size_t)first * 7, c, dF + (size_t)first * 27, dnsol + first, VO_MEM_DEVICE))) return rc;
         if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)first * 27, 3 * c, thr, dcounts + 3 * (size_t)first, nullptr, VO_MEM_DEVICE))) return rc;
-        VO_HIP_CHECK(hipMemcpyAsync(counts, dcounts + 3 * (size_t)first, (size_t)c * 12, hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP_CHECK(hipMemcpyAsync(counts + 3 * 4096, dnsol + first, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // read back by kernels that write the page-locked area (a copy engine's hand-over from the compute queue costs more
+        // than these few KB take)
+        if ((rc = vo_download_async(ctx, counts, dcounts + 3 * (size_t)first, (size_t)c * 12))) return rc;
+        if ((rc = vo_download_async(ctx, counts + 3 * 4096, dnsol + first, (size_t)c * 4))) return rc;
         VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const int32_t *nsol = counts + 3 * 4096;
         uint8_t *used = (uint8_t *)(counts + 4 * 4096);
@@ -387,7 +389,7 @@ extern "C" int vo_find_fundamental_ransac(vo_ctx *ctx, const float *m1, const fl
     if ((rc = vo_score_fundamental(ctx, d1, d2, n, dF + (size_t)win * 9, 1, thr, dcounts, dmask, VO_MEM_DEVICE))) return rc;
     VO_HIP_CHECK(hipMemcpyAsync(pin_F, dF + (size_t)win * 9, 72, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(hipMemcpyAsync(pin_good, dcounts, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(hipMemcpyAsync(pin_mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = vo_download_async(ctx, pin_mask, dmask, (size_t)n))) return rc;
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(F_out, pin_F, 72);
     memcpy(inlier_mask, pin_mask, (size_t)n);
