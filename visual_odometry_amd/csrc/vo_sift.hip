@@ -429,8 +429,11 @@ __global__ __launch_bounds__(256) void sift_join_lists_kernel(const vo_sift_keyp
     for (int b = threadIdx.x; b < SIFT_JOB_BINS; b += 256) radius_hist[blockIdx.x * SIFT_JOB_BINS + b] = hist[b];
 }
 
-// One wavefront per candidate.
-#define SIFT_ORI_CHUNK 1024
+// One wavefront per candidate.  The kernel waits more than it computes (dependent reads of the Newton steps, the
+// barrier between forming and adding a chunk's samples), so small chunks -- less LDS, more wavefronts per CU -- win.
+#ifndef SIFT_ORI_CHUNK
+#define SIFT_ORI_CHUNK 512
+#endif
 __global__ __launch_bounds__(64) void sift_refine_kernel(const float *__restrict__ pool, SiftOctaves O, const SiftCand *__restrict__ cand,
                                                         const int *__restrict__ n_cand, int cand_cap, float contrast_thr,
                                                         float edge_thr, float sigma, vo_sift_keypoint *__restrict__ out,
