@@ -156,15 +156,18 @@ __global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t *__res
     dst[(size_t)y * W + x] = r0 * b0 + r1 * b1;
 }
 
-// Row pass: a workgroup stages 256 + 2r pixels of one row in LDS (reflected at the ends), a lane adds its taps
-// left to right.
-__global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-                                                            SiftKernel K)
+// Row pass: a workgroup stages SIFT_ROW_SEG + 2r pixels of one row in LDS (reflected at the ends), a lane adds its
+// taps left to right.
+#ifndef SIFT_ROW_SEG
+#define SIFT_ROW_SEG 256
+#endif
+__global__ __launch_bounds__(SIFT_ROW_SEG) void sift_blur_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                                     SiftKernel K)
 {
-    __shared__ float row[256 + SIFT_MAX_TAPS + 1];
-    const int y = blockIdx.y, x0 = blockIdx.x * 256, r = K.n >> 1;
+    __shared__ float row[SIFT_ROW_SEG + SIFT_MAX_TAPS + 1];
+    const int y = blockIdx.y, x0 = blockIdx.x * SIFT_ROW_SEG, r = K.n >> 1;
     const float *s = src + (size_t)y * w;
-    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) row[i] = s[reflect101(x0 - r + i, w)];
+    for (int i = threadIdx.x; i < SIFT_ROW_SEG + 2 * r; i += SIFT_ROW_SEG) row[i] = s[reflect101(x0 - r + i, w)];
     __syncthreads();
     const int x = x0 + threadIdx.x;
     if (x >= w) return;
@@ -807,7 +810,7 @@ static int sift_blur(vo_ctx *ctx, const float *src, float *dst, float *tmp, int 
     SiftKernel K;
     int rc = sift_gauss_kernel(sigma, K);
     if (rc) return rc;
-    hipLaunchKernelGGL(sift_blur_rows_kernel, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, src, tmp, w, h, K);
+    hipLaunchKernelGGL(sift_blur_rows_kernel, dim3((w + SIFT_ROW_SEG - 1) / SIFT_ROW_SEG, h), dim3(SIFT_ROW_SEG), 0, ctx->stream, src, tmp, w, h, K);
     hipLaunchKernelGGL(sift_blur_cols_kernel, dim3((w + 63) / 64, (h + SIFT_COL_ROWS - 1) / SIFT_COL_ROWS), dim3(256), 0, ctx->stream,
                        (const float *)tmp, dst, w, h, K, src, diff);
     return VO_OK;
