@@ -35,6 +35,24 @@ def _same(kp, des, rk, rd):
         assert des.dtype == np.float32 and des.shape == rd.shape and np.array_equal(des, rd)
 
 
+@pytest.mark.parametrize("shape,layers,sigma", [((30, 400), 5, 2.0), ((400, 26), 3, 1.2), ((64, 64), 8, 2.4), ((150, 210), 2, 1.6)])
+def test_scale_space_small_octaves_other_parameters(ctx, oracle, shape, layers, sigma):
+    """The last octaves come from one launch that keeps the layers in LDS with reflected borders as wide as the largest blur:
+    thin images (a border wider than the image, octaves that do and do not fit that launch), other layer counts and sigmas."""
+    from visual_odometry_amd import hip
+    img = synth.frame_pair(shape, seed=11)[0]
+    n_oct = oracle.lib().vo_or_sift_num_octaves(shape[1], shape[0])
+    for o in range(max(0, n_oct - 5), n_oct):
+        for i in range(layers + 3):
+            got = hip.sift_scale_space_image(ctx, img, o, i, n_octave_layers=layers, sigma=sigma)
+            ref = oracle.sift_pyramid_image(img, o, i, n_octave_layers=layers, sigma=sigma)
+            assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (o, i)
+        for i in range(layers + 2):
+            got = hip.sift_scale_space_image(ctx, img, o, i, dog=True, n_octave_layers=layers, sigma=sigma)
+            ref = oracle.sift_pyramid_image(img, o, i, dog=True, n_octave_layers=layers, sigma=sigma)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (o, i)
+
+
 @pytest.mark.parametrize("shape,seed", [((240, 320), 3), ((97, 131), 5), ((376, 1241), 2021), ((33, 300), 7)])
 def test_detect_compute_bit_exact(ctx, oracle, shape, seed):
     from visual_odometry_amd import hip
