@@ -114,6 +114,28 @@ def test_device_inputs_and_unseen_landmarks(oracle, ctx):
     assert na < ca
 
 
+def test_parameter_vector_beyond_the_page_locked_paths(ctx):
+    """A parameter vector of more than 1 MiB (the bound of the context's page-locked ring and result area) takes the
+    fallback copies in vo_ba_linearize / vo_ba_params: the same cost as the residual call, the vector back unchanged."""
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=4, P=400, visibility=1.0, seed=4)
+    F, K = pb["F"], pb["K"]
+    P = 50000                                                      # 6F + 3P doubles = 1.2 MB; landmarks 400.. are unobserved
+    x = np.hstack([pb["x"], np.random.default_rng(0).normal(size=3 * (P - pb["P"]))])
+    ci, pi, obs = pb["ci"], pb["pi"], pb["obs"].astype(np.float64)
+    s = hip.BaSolver(ctx, F, P, ci, pi, obs, K, _start(F, ci))
+    cost = s.linearize(x)
+    _, want = hip.ba_residual(ctx, x, F, P, ci, pi, obs, K)
+    assert cost == pytest.approx(want, rel=1e-12)
+    np.testing.assert_array_equal(s.params(), x)
+    new_cost, solved = s.try_step(1e-3)
+    assert solved and new_cost < cost
+    moved = s.params(True)
+    np.testing.assert_array_equal(moved[6 * F + 3 * pb["P"]:], x[6 * F + 3 * pb["P"]:])      # unobserved landmarks stay
+    assert np.abs(moved - x).max() > 0
+    s.close()
+
+
 def test_empty_window_state_errors_and_bad_indices(ctx):
     from visual_odometry_amd import hip
     from visual_odometry_amd._lib import VoError
