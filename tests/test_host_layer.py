@@ -189,3 +189,50 @@ def test_reference_module_names_resolve_to_the_mirror():
             ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+class _ScriptedSolver:
+    """Stands in for hip.BaSolver: linearize returns the first cost, every try_step the next one of a script."""
+
+    def __init__(self, costs, O=10):
+        self.costs, self.O, self.tried, self.accepted, self.closed = list(costs), O, [], 0, False
+
+    def linearize(self, x):
+        return self.costs.pop(0)
+
+    def try_step(self, lam):
+        self.tried.append(lam)
+        c = self.costs.pop(0)
+        return (c, True) if c is not None else (float("nan"), False)
+
+    def accept(self):
+        self.accepted += 1
+
+    def params(self):
+        return "x*"
+
+    def close(self):
+        self.closed = True
+
+
+def test_levenberg_marquardt_loop_endings():
+    ba = bundleAdjustment.BundleAdjustment(np.eye(3))
+    # accepted steps until one gains less than ftol of the cost
+    s = _ScriptedSolver([100.0, 50.0, 49.0, 48.9999])
+    assert ba._levenberg_marquardt("x0", s, 50, 1e-4) == "x*" and s.accepted == 3 and len(s.tried) == 3 and s.closed
+    assert s.tried[1] == pytest.approx(s.tried[0] / 3)                      # damping relaxed after an accepted step
+    # a rejected step (and one that could not be solved) strengthens the damping tenfold
+    s = _ScriptedSolver([100.0, 120.0, None, 60.0, 59.9999])
+    ba._levenberg_marquardt("x0", s, 50, 1e-4)
+    assert s.accepted == 2 and s.tried[1] == pytest.approx(10 * s.tried[0]) and s.tried[2] == pytest.approx(100 * s.tried[0])
+    # a rejected step that moved the cost by less than ftol ends the window at once ...
+    s = _ScriptedSolver([100.0, 50.0, 50.004, 49.0])
+    ba._levenberg_marquardt("x0", s, 50, 1e-4)
+    assert s.accepted == 1 and len(s.tried) == 2 and s.closed
+    # ... a larger increase does not: ten rejected steps in a row do
+    s = _ScriptedSolver([100.0] + [101.0] * 10 + [1.0])
+    ba._levenberg_marquardt("x0", s, 50, 1e-4)
+    assert s.accepted == 0 and len(s.tried) == 10 and s.closed
+    # an empty window returns the start and still closes the solver
+    s = _ScriptedSolver([], O=0)
+    assert ba._levenberg_marquardt("x0", s, 50, 1e-4) == "x0" and s.closed
