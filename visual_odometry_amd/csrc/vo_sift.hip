@@ -595,6 +595,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     __shared__ float s_scale[4][2];
     float (*s_dst)[d * d * n] = reinterpret_cast<float (*)[d * d * n]>(&s_v[0][0][0]);      // 4 x 128 floats <= 4 x 26 x 5
     __shared__ unsigned long long s_touch[4][16];       // per owner: the waiting samples that touch its cell, one bit each
+    __shared__ int s_queue[4][64];                      // positions inside the grid, waiting for a lane: (row offset, column offset) as two shorts
     const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
     const int job = blockIdx.x * 4 + g;
     const bool has = job < n_jobs;
@@ -608,62 +609,76 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
     const int max_len = max(max(__shfl(len, 0), __shfl(len, 16)), max(__shfl(len, 32), __shfl(len, 48)));
     const int my_cell = ((gl >> 2) + 1) * (d + 2) + (gl & 3) + 1;      // index of this lane's cell in the 6x6 grid
     float *mine = hist[g] + gl * (n + 2);
+    // Only about half of the window's positions fall inside the rotated 4x4 grid, so the positions are tested first
+    // (cheap: the rotation and two range checks) and the survivors queued in raster order; the gradient, weight and
+    // angle work then takes sixteen queued positions at a time, one per lane, with no lane idle.
     int filled = 0;                                                     // samples waiting in this group's buffer
-    int wi = gl / side, wj = gl - wi * side;                            // row and column of this lane's window position
+    int qn = 0, qhead = 0;                                              // positions waiting in this group's queue (64 slots, circular)
+    int wi = gl / side, wj = gl - wi * side;                            // row and column of this lane's next window position
     __builtin_amdgcn_wave_barrier();
-    for (int base = 0; base < max_len; base += 16) {
-        const int idx = base + gl;
-        bool ok = false;
-        float v[5];
-        int cell = 0, row6 = 0, col6 = 0;      // first of the (up to) four cells the sample touches, in the 6x6 grid
-        const int i = wi - radius, j = wj - radius;
-        wj += 16;                               // the next position, sixteen further on in raster order
-        while (wj >= side) { wj -= side; ++wi; }
-        if (idx < len) {
+    for (int base = 0;;) {
+        if (base < max_len && __ballot(qn > 31) == 0) {                 // room for 32 more positions in every group's queue
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int idx = base + 16 * sub + gl;
+                const int i = wi - radius, j = wj - radius;
+                wj += 16;                           // the next position, sixteen further on in raster order
+                while (wj >= side) { wj -= side; ++wi; }
+                bool ok = false;
+                if (idx < len) {
+                    const float c_rot = j * jb.cos_t - i * jb.sin_t, r_rot = j * jb.sin_t + i * jb.cos_t;
+                    const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+                    const int r = jb.py + i, c = jb.px + j;
+                    ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+                }
+                const unsigned gm = (unsigned)(__ballot(ok) >> (16 * g)) & 0xffffu;
+                if (ok) s_queue[g][(qhead + qn + __popc(gm & ((1u << gl) - 1u))) & 63] = (i & 0xffff) | (int)((unsigned)j << 16);
+                qn += __popc(gm);
+            }
+            base += 32;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool last = base >= len;              // this group's window has been walked
+        const int take = qn >= 16 ? 16 : (last ? qn : 0);
+        if (gl < take) {
+            const int packed = s_queue[g][(qhead + gl) & 63];
+            const int i = (int)(short)(packed & 0xffff), j = packed >> 16;
             const float c_rot = j * jb.cos_t - i * jb.sin_t, r_rot = j * jb.sin_t + i * jb.cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = jb.py + i, c = jb.px + j;
-            ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-            if (ok) {
-                const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
-                const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
-                const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-                float obin = (sift_atan2_deg(dy, dx) - jb.ori) * bins_per_rad;
-                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-                const int r0 = sift_floor(rbin), c0 = sift_floor(cbin);
-                int o0 = sift_floor(obin);
-                rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                v[0] = v_rc00; v[1] = v_rc01; v[2] = v_rc10; v[3] = v_rc11;      // [r][c] -> index 2r + c
-                v[4] = obin;
-                cell = (((r0 + 1) * (d + 2) + c0 + 1) << 8) | o0;          // first of the four cells it touches, orientation bin
-                row6 = r0 + 1;
-                col6 = c0 + 1;
-            }
-        }
-        // compact in raster order behind the samples already waiting in the group's buffer
-        const unsigned gm = (unsigned)(__ballot(ok) >> (16 * g)) & 0xffffu;
-        if (ok) {
-            const int at = filled + __popc(gm & ((1u << gl) - 1u));
-            s_cell[g][at] = cell;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) s_v[g][at][q] = v[q];
+            const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
+            const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
+            const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (sift_atan2_deg(dy, dx) - jb.ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const int r0 = sift_floor(rbin), c0 = sift_floor(cbin);
+            int o0 = sift_floor(obin);
+            rbin -= r0; cbin -= c0; obin -= o0;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const int at = filled + gl;             // raster order: the queue's order
+            s_cell[g][at] = (((r0 + 1) * (d + 2) + c0 + 1) << 8) | o0;      // first of the four cells it touches, orientation bin
+            s_v[g][at][0] = v_rc00; s_v[g][at][1] = v_rc01; s_v[g][at][2] = v_rc10; s_v[g][at][3] = v_rc11;      // [r][c] -> index 2r + c
+            s_v[g][at][4] = obin;
             // tell the owners of the inner cells it touches (bit `at` of their word: order-free, so atomics may land in any order)
 #pragma unroll
             for (int dr = 0; dr < 2; ++dr)
 #pragma unroll
                 for (int dc = 0; dc < 2; ++dc) {
-                    const int rr = row6 + dr, cc = col6 + dc;
+                    const int rr = r0 + 1 + dr, cc = c0 + 1 + dc;
                     if (rr >= 1 && rr <= d && cc >= 1 && cc <= d) atomicOr(&s_touch[g][(rr - 1) * d + cc - 1], 1ull << at);
                 }
         }
-        filled += __popc(gm);
+        qhead = (qhead + take) & 63;
+        qn -= take;
+        filled += take;
         // when one group's buffer is full (or its window ends) all four groups empty theirs: the owners' loops then
         // run side by side instead of one group at a time
-        if (__ballot(filled > SIFT_DESC_BUF - 16 || (base + 16 >= len && filled > 0)) != 0) {
+        if (__ballot(filled > SIFT_DESC_BUF - 16 || (last && qn == 0 && filled > 0)) != 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -688,6 +703,7 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(const float *__rest
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (base >= max_len && __ballot(qn > 0 || filled > 0) == 0) break;
     }
     // circular orientation bins, then the 128 values in (row, column, bin) order
     mine[0] += mine[n];
