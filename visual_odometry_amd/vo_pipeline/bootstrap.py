@@ -22,6 +22,25 @@ from .featureMatching import FeatureMatcher, MatcherType
 from .poseEstimation import PoseEstimation
 
 
+class _DescriptorRows:
+    """Rows of a descriptor matrix picked by index; a matrix that lives on the GPU is read only when the rows are
+    asked for (the pipeline itself never looks at the descriptors of a bootstrap's correspondences, and fetching
+    them costs more than the RANSAC call they accompany)."""
+
+    def __init__(self, source, rows):
+        self.source, self.rows = source, np.asarray(rows)
+
+    def __getitem__(self, selection):
+        return _DescriptorRows(self.source, self.rows[selection])
+
+    def numpy(self) -> np.ndarray:
+        if isinstance(self.source, np.ndarray):
+            return np.asarray(self.source, np.float32)[self.rows]
+        import torch
+        rows = torch.from_numpy(np.ascontiguousarray(self.rows, dtype=np.int64)).to(self.source.device)
+        return self.source[rows].cpu().numpy()
+
+
 class BootstrapInitializer:
     def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100, features=None,
                  correspondences: str = "sift"):
@@ -40,15 +59,34 @@ class BootstrapInitializer:
         F, pts1, pts2, pts_des1, pts_des2 = self._estimate_fundamental()
         self.F = F
         self.pts1, self.pts2 = pts1, pts2
-        self.pts_des1, self.pts_des2 = pts_des1, pts_des2
         T, point_cloud, mask = self._transform_matrix(self.F, self.pts1, self.pts2)
         self.T = T
         self.point_cloud = point_cloud
         self.pts1 = self.pts1[mask]
         self.pts2 = self.pts2[mask]
-        self.pts_des1 = self.pts_des1[mask]
-        self.pts_des2 = self.pts_des2[mask]
+        self._des1, self._des2 = pts_des1[mask], pts_des2[mask]
         self.point_cloud = self.point_cloud[mask]
+
+    # descriptors of the surviving correspondences, (n,128) float32 as in the reference (bootstrap.py:49-50)
+    @property
+    def pts_des1(self) -> np.ndarray:
+        if isinstance(self._des1, _DescriptorRows):
+            self._des1 = self._des1.numpy()
+        return self._des1
+
+    @pts_des1.setter
+    def pts_des1(self, value):
+        self._des1 = value
+
+    @property
+    def pts_des2(self) -> np.ndarray:
+        if isinstance(self._des2, _DescriptorRows):
+            self._des2 = self._des2.numpy()
+        return self._des2
+
+    @pts_des2.setter
+    def pts_des2(self, value):
+        self._des2 = value
 
     @staticmethod
     def findFundamentalMat(pts0: np.ndarray, pts1: np.ndarray, ransacReprojThreshold: float, confidence: float,
@@ -77,7 +115,7 @@ class BootstrapInitializer:
             td = idx[qd, 0].long()
             q, t = qd.cpu().numpy(), td.cpu().numpy()
             logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
-            return kp0[q], kp1[t], des0[qd].cpu().numpy(), des1[td].cpu().numpy()
+            return kp0[q], kp1[t], _DescriptorRows(des0, q), _DescriptorRows(des1, t)
         q = np.nonzero(keep)[0]
         t = idx[q, 0]
         logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
