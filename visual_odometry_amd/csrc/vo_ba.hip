@@ -1999,7 +1999,7 @@ static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **o
             ctx->ba_pool = nullptr;
             ctx->ba_pool_bytes = 0;
         }
-        const size_t room = tot + tot / 4;       // windows of the next keyframes fit without another allocation
+        const size_t room = 2 * tot;             // windows grow from keyframe to keyframe: the next ones fit without another allocation
         hipError_t e = hipMalloc((void **)&ba->pool, room);
         if (e != hipSuccess) {
             e = hipMalloc((void **)&ba->pool, tot);
