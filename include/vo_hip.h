@@ -347,6 +347,40 @@ int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const uint8_t *n
  * survivors, 3 the same because the device-side sampler or replay could not vouch for its result. */
 int vo_track_pnp_path(const vo_ctx *ctx);
 
+/* ---- the tracked frame of many independent streams in one launch chain ---------------------------------
+ * vo_track_pnp_batch is vo_track_pnp (above; vo_pipeline/continuousVO.py:160-180 with
+ * vo_pipeline/poseEstimation.py:51-77 and 116-133) for every image pair of two batched pyramids at once:
+ * stream b tracks image b of `prev` into image b of `next` (both built), filters its rows by status and runs
+ * cv.solvePnPRansac's loop and refit on its survivors.  The reference runs one camera stream per process; a server
+ * that runs many of them batches their frames here, with one launch chain and ONE synchronisation for all streams.
+ * The outcome per stream equals vo_track_pnp on that stream alone (given the same tracker kernel, which the library
+ * picks by the number of keypoints in the call): tracked points, status, pose, inlier mask, counts, generator state.
+ * prev_pts (batch,n,2) float32, landmarks (batch,n,3) float32, next_pts (batch,n,2) float32, status (batch,n)
+ * uint8, inlier_mask (batch,n) uint8 follow `mem`; a stream with fewer than n keypoints pads with points outside
+ * the image (they lose their status and drop out).  K (3,3) float64 is shared by the streams (host pointer).
+ * Host arrays of `batch` entries: rng_state (in/out cv::RNG states; NULL = every stream starts from OpenCV's
+ * initial 2^64-1, as each cv.solvePnPRansac call does), Rt_out (batch,12) float64 (a stream without pose keeps its
+ * rows untouched), n_tracked, n_inliers (0: no pose), path (may be NULL; per stream as vo_track_pnp_path).
+ * Streams whose loop outlives the first 256 samples are finished one by one through vo_solve_pnp_ransac after the
+ * synchronisation.
+ *
+ * vo_track_pnp_batch_begin / _finish are the two halves: begin enqueues everything on the context's stream and
+ * returns without waiting (rng_state is read there; with VO_MEM_HOST the three output arrays must stay valid
+ * until finish); finish waits for the chain, re-checks each stream's loop on the host and writes the host outputs.
+ * A caller with several contexts begins a batch on each before finishing the first, so that their chains overlap
+ * on the device.  One batch per context may be in flight.
+ */
+int vo_track_pnp_batch(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
+                       int n, const vo_klt_params *params, const double *K, double thr, double conf, int max_iters,
+                       int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
+                       uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int32_t *path, int mem);
+int vo_track_pnp_batch_begin(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts,
+                             const float *landmarks, int n, const vo_klt_params *params, const double *K, double thr,
+                             double conf, int max_iters, int refine_iters, const uint64_t *rng_state, float *next_pts,
+                             uint8_t *status, uint8_t *inlier_mask, int mem);
+int vo_track_pnp_batch_finish(vo_ctx *ctx, uint64_t *rng_state, double *Rt_out, int32_t *n_tracked, int32_t *n_inliers,
+                              int32_t *path);
+
 /* ---- corner mask and sub-pixel refinement of FeatureExtractor.harris -------------------------
  * vo_harris_mask replaces cv.cornerHarris + cv.dilate + cv.threshold + np.uint8
  * (vo_pipeline/featureExtraction.py:40-43): mask = 255 where the 3x3 maximum of the response

@@ -87,6 +87,11 @@ SIGNATURES = {
                                     ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), c_vp, c_vp, c_f64p, c_vp,
                                     ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
     "vo_track_pnp_path": (ctypes.c_int, [c_vp]),
+    "vo_track_pnp_batch": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_f64p, c_vp, c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_track_pnp_batch_begin": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, ctypes.c_double,
+                                                ctypes.c_double, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_track_pnp_batch_finish": (ctypes.c_int, [c_vp, c_vp, c_f64p, c_vp, c_vp, c_vp]),
     "vo_find_fundamental_ransac": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                                   ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), c_f64p, c_vp,
                                                   ctypes.POINTER(ctypes.c_int32)]),

@@ -657,8 +657,21 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                                                                      int max_iters, double *__restrict__ out,
                                                                      const double *__restrict__ Rt_src, int sel,
                                                                      const int *__restrict__ sel_dev, const int *__restrict__ n_dev,
-                                                                     const int *__restrict__ mask_row)
+                                                                     const int *__restrict__ mask_row, vo_batch_strides bs)
 {
+    // blockIdx.x: the problem (a stream of a batched frame), one workgroup each; its arrays start bs.work / bs.out /
+    // bs.mask bytes after the problem before
+    if (bs.count > 1) {
+        const size_t b = blockIdx.x;
+        X = (const float *)((const char *)X + b * bs.work);
+        x = (const float *)((const char *)x + b * bs.work);
+        if (mask) mask += b * bs.mask;
+        out = (double *)((char *)out + b * bs.out);
+        if (Rt_src) Rt_src = (const double *)((const char *)Rt_src + b * bs.work);
+        if (sel_dev) sel_dev = (const int *)((const char *)sel_dev + b * bs.out);
+        if (n_dev) n_dev = (const int *)((const char *)n_dev + b * bs.out);
+        if (mask_row) mask_row = (const int *)((const char *)mask_row + b * bs.work);
+    }
     // every lane's 28 partial sums, one row per sum: consecutive lanes of a row are consecutive doubles, and a row starts
     // REFINE_RED doubles further into the 256-byte LDS line than the row before it, so the rows that the reducing lanes of
     // a half-wavefront read at once fall on different banks
@@ -878,7 +891,7 @@ int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, c
     if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
     double *d_out = (double *)p;
     hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
-                       (const double *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, (const int *)nullptr);
+                       (const double *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, vo_batch_strides());
     VO_HIP_CHECK(hipGetLastError());
     VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;
@@ -891,7 +904,7 @@ int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, c
 // enqueued here; no synchronisation.
 int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
                                  const int *mask_row, const double *K, const double *dRt, int sel, const int *sel_dev,
-                                 int max_iters, double *host_out, double *d_out)
+                                 int max_iters, double *host_out, double *d_out, const vo_batch_strides &bs)
 {
     BaK Kv;
     memcpy(Kv.k, K, sizeof(Kv.k));
@@ -899,12 +912,14 @@ int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, 
     int rc;
     void *p;
     const bool own = d_out == nullptr;
+    VO_REQUIRE(bs.count == 1 || !own, "vo_refine_pose: batched refits leave their results on the device");
+    if (bs.count <= 0) return VO_OK;
     if (own) {
         if ((rc = vo_stage_reserve(ctx, 3, 64, &p))) return rc;
         d_out = (double *)p;
     }
-    hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
-                       dRt, sel, sel_dev, n_dev, mask_row);
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(bs.count), dim3(REFINE_THREADS), 0, ctx->stream, dX, dx, dmask, n, Kv, start, max_iters, d_out,
+                       dRt, sel, sel_dev, n_dev, mask_row, bs);
     VO_HIP_CHECK(hipGetLastError());
     if (own) VO_HIP_CHECK(hipMemcpyAsync(host_out, d_out, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;

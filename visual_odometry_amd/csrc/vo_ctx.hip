@@ -76,6 +76,7 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
     for (auto &b : ctx->stage)
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->ba_pool) (void)hipFree(ctx->ba_pool);
+    vo_frame_batch_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->res_area) (void)hipHostFree(ctx->res_area);

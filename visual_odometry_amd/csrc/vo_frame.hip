@@ -16,10 +16,13 @@
 #include "vo_internal.h"
 #include <math.h>
 #include <float.h>
+#include <new>
+#include <vector>
 
 #define FS_THREADS 1024
 #define FS_SAMPLES 256                      // samples of the first chunk
 #define FS_DRAWS (4 * FS_SAMPLES + 512)     // raw generator outputs kept on the device: room for 512 rejected draws
+#define FS_STAGE1 32                        // batched frames: samples solved and scored before the loop's bound is looked at
 
 // One subset of four distinct indices drawn from position p of the raw generator output, as
 // RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another draw.
@@ -37,25 +40,45 @@ __device__ static inline int frame_draw_subset(const uint32_t *raw, int p, uint3
     return have == 4 && p < FS_DRAWS ? p : FS_DRAWS;
 }
 
-// Everything between the tracker and the minimal solver, in one workgroup:
+// Everything between the tracker and the minimal solver, one workgroup per stream (blockIdx.x; a single frame is
+// one stream):
 //  * rows with status 1 are compacted in order (landmarks and tracked points side by side; orig[j] = input row of
 //    survivor j), the full-length inlier mask and the candidates' inlier counts are cleared;
 //  * subsets 0 .. c0-1 are drawn.  Where subset i starts depends on the rejections before it; "the position after
 //    the subset that starts at p" is a function of p alone, so the starts are the orbit of 0 under it: every position
 //    computes its successor, log2(c0) rounds of pointer doubling give hops of 1, 2, 4, ... subsets, and sample i
 //    combines the hops of its set bits.
+// states: the generator's state after 0, 1, ..., FS_DRAWS draws (a draw is the low half of the state after it);
+// stream b reads its own run of them, states_stride entries after stream b-1's (0: all streams draw alike).
+// starts (optional, c0 + 1 entries): how many draws precede subset i.
 __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
                                                                 const float *__restrict__ pts, int n,
-                                                                const uint32_t *__restrict__ raw_g, int c0, float *__restrict__ Xc,
-                                                                float *__restrict__ xc, int *__restrict__ orig,
+                                                                const uint64_t *__restrict__ states, size_t states_stride, int c0,
+                                                                float *__restrict__ Xc, float *__restrict__ xc, int *__restrict__ orig,
                                                                 vo_frame_meta *__restrict__ meta, int *__restrict__ counts,
-                                                                uint8_t *__restrict__ full, int *__restrict__ subsets)
+                                                                uint8_t *__restrict__ full, int *__restrict__ subsets,
+                                                                unsigned short *__restrict__ starts, vo_batch_strides bs)
 {
     __shared__ int wcount[FS_THREADS / 64];
     __shared__ uint32_t raw[FS_DRAWS];
     __shared__ unsigned short hop[2][FS_DRAWS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = raw_g[p];
+    {
+        const size_t b = blockIdx.x;
+        status += b * (size_t)n;
+        X += 3 * b * (size_t)n;
+        pts += 2 * b * (size_t)n;
+        full += b * bs.mask;
+        states += b * states_stride;
+        Xc = (float *)((char *)Xc + b * bs.work);
+        xc = (float *)((char *)xc + b * bs.work);
+        orig = (int *)((char *)orig + b * bs.work);
+        subsets = (int *)((char *)subsets + b * bs.work);
+        if (starts) starts = (unsigned short *)((char *)starts + b * bs.work);
+        meta = (vo_frame_meta *)((char *)meta + b * bs.out);
+        counts = (int *)((char *)counts + b * bs.out);
+    }
+    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = (uint32_t)states[p + 1];
     if (tid <= c0) counts[tid] = 0;
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
@@ -88,9 +111,12 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         meta->best = 0;
         meta->niters = 0;
         meta->overflow = 0;
+        meta->bound0 = 0x7fffffff;
+        meta->state = states[0];
     }
     if (m < 4) {
         if (tid < c0) { subsets[4 * tid] = 0; subsets[4 * tid + 1] = 0; subsets[4 * tid + 2] = 0; subsets[4 * tid + 3] = 0; }
+        if (starts && tid <= c0) starts[tid] = 0;
         return;
     }
     int idx[4];
@@ -112,6 +138,10 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
             idx[0] = idx[1] = idx[2] = idx[3] = 0;
         }
         subsets[4 * tid] = idx[0]; subsets[4 * tid + 1] = idx[1]; subsets[4 * tid + 2] = idx[2]; subsets[4 * tid + 3] = idx[3];
+        if (starts) {
+            starts[tid] = (unsigned short)pos;
+            if (tid == c0 - 1) starts[c0] = (unsigned short)end;
+        }
     }
 }
 
@@ -128,26 +158,13 @@ __device__ static int frame_update_num_iters(double p, double ep, int model_poin
     return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : (int)lrint(num / denom);
 }
 
-// The winner of the first chunk and its inlier mask.  Every wavefront replays OpenCV's sequential loop over the
-// chunk's candidates for itself (candidate c improves the best when its count exceeds max(best, 3) and c is still
-// below the iteration bound, which every improvement recomputes; only improvements change the state, so per 64
-// candidates the wavefront jumps from one improvement to the next), then scores its share of the survivors against
-// the winner with the expression of the scoring kernel and writes the mask at the survivors' input rows.
-#define FM_WAVES 4
-#define FM_POINTS 1024      // survivors per workgroup
-__global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid,
-                                                                   int c0, int max_iters, double conf, const double *__restrict__ Rt,
-                                                                   const float *__restrict__ Xc, const float *__restrict__ xc,
-                                                                   const int *__restrict__ orig, double fx, double fy, double cx,
-                                                                   double cy, float t, vo_frame_meta *__restrict__ meta,
-                                                                   uint8_t *__restrict__ full, int m_host,
-                                                                   int *__restrict__ out_counts, uint8_t *__restrict__ out_valid)
+// OpenCV's sequential loop over candidates 0 .. c0-1 (one per iteration, valid[c] == 0: none), replayed by one
+// wavefront: candidate c improves the best when its count exceeds max(best, 3) and c is still below the iteration
+// bound, which every improvement recomputes.  Only improvements change the state, so per 64 candidates the
+// wavefront jumps from one improvement to the next.
+__device__ static void frame_replay(const int *__restrict__ counts, const uint8_t *__restrict__ valid, int c0, int m, double conf,
+                                    int lane, int &niters, int &best, int &best_c)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m = m_host >= 0 ? m_host : meta->m;
-    if (out_counts && blockIdx.x == 0)
-        for (int c = threadIdx.x; c < c0; c += 64 * FM_WAVES) { out_counts[c] = counts[c]; out_valid[c] = valid[c]; }
-    int niters = max_iters, best = -1, best_c = -1;
     bool stop = m < 4;
     for (int r = 0; r * 64 < c0 && !stop; ++r) {
         const int c = r * 64 + lane;
@@ -163,6 +180,62 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
             niters = frame_update_num_iters(conf, (double)(m - best) / m, 4, niters);
         }
     }
+}
+
+// Batched frames solve and score their first chunk in two stages: after the first c1 candidates this kernel (one
+// wavefront per stream) leaves the loop's iteration bound in meta->bound0.  The bound only shrinks, so no candidate
+// from bound0 on can matter any more, and the second stage's launches skip those beyond it (one more is kept: the
+// host re-checks the loop with its own libm, whose bound may round the other way).
+__global__ __launch_bounds__(64) void frame_bound_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid, int c1,
+                                                         int max_iters, double conf, vo_frame_meta *__restrict__ meta,
+                                                         vo_batch_strides bs)
+{
+    const size_t b = blockIdx.x;
+    counts = (const int *)((const char *)counts + b * bs.out);
+    valid += b * bs.out;
+    meta = (vo_frame_meta *)((char *)meta + b * bs.out);
+    int niters = max_iters, best = -1, best_c = -1;
+    frame_replay(counts, valid, c1, meta->m, conf, threadIdx.x, niters, best, best_c);
+    if (threadIdx.x == 0) meta->bound0 = niters;
+}
+
+// The winner of the first chunk and its inlier mask.  Every wavefront replays the loop over the chunk's candidates
+// for itself, then scores its share of the survivors against the winner with the expression of the scoring kernel
+// and writes the mask at the survivors' input rows.  blockIdx.y: the stream.  starts / states (optional): the draws
+// that precede each subset and the generator's states, from which the state after the loop's iterations follows.
+#define FM_WAVES 4
+#define FM_POINTS 1024      // survivors per workgroup
+__global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__restrict__ counts, const uint8_t *__restrict__ valid,
+                                                                   int c0, int max_iters, double conf, const double *__restrict__ Rt,
+                                                                   const float *__restrict__ Xc, const float *__restrict__ xc,
+                                                                   const int *__restrict__ orig, double fx, double fy, double cx,
+                                                                   double cy, float t, vo_frame_meta *__restrict__ meta,
+                                                                   uint8_t *__restrict__ full, int m_host,
+                                                                   int *__restrict__ out_counts, uint8_t *__restrict__ out_valid,
+                                                                   const unsigned short *__restrict__ starts,
+                                                                   const uint64_t *__restrict__ states, size_t states_stride,
+                                                                   vo_batch_strides bs)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (bs.count > 1) {
+        const size_t b = blockIdx.y;
+        counts = (const int *)((const char *)counts + b * bs.out);
+        valid += b * bs.out;
+        Rt = (const double *)((const char *)Rt + b * bs.work);
+        Xc = (const float *)((const char *)Xc + b * bs.work);
+        xc = (const float *)((const char *)xc + b * bs.work);
+        if (orig) orig = (const int *)((const char *)orig + b * bs.work);
+        meta = (vo_frame_meta *)((char *)meta + b * bs.out);
+        full += b * bs.mask;
+        if (starts) starts = (const unsigned short *)((const char *)starts + b * bs.work);
+        if (states) states += b * states_stride;
+    }
+    const int m = m_host >= 0 ? m_host : meta->m;
+    if (blockIdx.x * FM_POINTS >= m && blockIdx.x > 0) return;        // no survivors for this workgroup
+    if (out_counts && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < c0; c += 64 * FM_WAVES) { out_counts[c] = counts[c]; out_valid[c] = valid[c]; }
+    int niters = max_iters, best = -1, best_c = -1;
+    frame_replay(counts, valid, c0, m, conf, lane, niters, best, best_c);
     if (blockIdx.x == 0 && wv == 0) {
         if (lane == 0) {
             meta->m = m;
@@ -170,6 +243,7 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
             meta->best = best_c >= 0 ? best : 0;
             meta->niters = niters;
             if (m_host >= 0) meta->overflow = 0;
+            if (starts && m >= 4 && niters <= c0) meta->state = states[starts[niters]];
         }
         if (best_c >= 0 && lane < 12) meta->Rt[lane] = Rt[12 * (int64_t)best_c + lane];
     }
@@ -185,15 +259,16 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
 int vo_pnp_first_chunk_tail(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, int m_host, const int *row,
                             const int32_t *dcounts, const uint8_t *dvalid, int c0, int max_iters, double conf, const double *K,
                             double thr, const double *dRt, vo_frame_meta *d_meta, int32_t *out_counts, uint8_t *out_valid,
-                            uint8_t *d_mask, int refine_iters, double *d_ref)
+                            uint8_t *d_mask, int refine_iters, double *d_ref, const vo_batch_strides &bs,
+                            const unsigned short *d_starts, const uint64_t *d_states, size_t states_stride)
 {
-    hipLaunchKernelGGL(frame_mask_kernel, dim3((n_cap + FM_POINTS - 1) / FM_POINTS), dim3(64 * FM_WAVES), 0, ctx->stream, dcounts,
-                       dvalid, c0, max_iters, conf, dRt, dX, dx, row, K[0], K[4], K[2], K[5], (float)(thr * thr), d_meta, d_mask,
-                       m_host, out_counts, out_valid);
+    hipLaunchKernelGGL(frame_mask_kernel, dim3((n_cap + FM_POINTS - 1) / FM_POINTS, bs.count), dim3(64 * FM_WAVES), 0, ctx->stream,
+                       dcounts, dvalid, c0, max_iters, conf, dRt, dX, dx, row, K[0], K[4], K[2], K[5], (float)(thr * thr), d_meta,
+                       d_mask, m_host, out_counts, out_valid, d_starts, d_states, states_stride, bs);
     VO_HIP_CHECK(hipGetLastError());
     if (refine_iters > 0)
         return vo_refine_pose_from_Rt_async(ctx, dX, dx, n_cap, m_host >= 0 ? nullptr : &d_meta->m, d_mask, row, K, dRt, 0, &d_meta->win,
-                                            refine_iters, nullptr, d_ref);
+                                            refine_iters, nullptr, d_ref, bs);
     return VO_OK;
 }
 
@@ -204,24 +279,31 @@ __global__ void frame_scatter_kernel(const int *__restrict__ orig, const uint8_t
     if (j < m) full[orig[j]] = mask_c[j];
 }
 
-// cv::RNG raw outputs from `state` on (multiply-with-carry), FS_DRAWS of them, kept on the device per context
-static int frame_raw_draws(vo_ctx *ctx, uint64_t state, const uint32_t **out)
+// cv::RNG (multiply-with-carry) states from `state` on: entry p = the state after p draws, FS_DRAWS + 1 of them,
+// kept on the device per context
+static void frame_states_from(uint64_t state, uint64_t *out)
+{
+    uint64_t s = state;
+    out[0] = s;
+    for (int k = 1; k <= FS_DRAWS; ++k) {
+        s = (uint64_t)(uint32_t)s * 4164903690u + (s >> 32);
+        out[k] = s;
+    }
+}
+
+static int frame_raw_draws(vo_ctx *ctx, uint64_t state, const uint64_t **out)
 {
     void *p;
     int rc;
-    if ((rc = vo_stage_reserve(ctx, 9, sizeof(uint32_t) * FS_DRAWS, &p))) return rc;
+    if ((rc = vo_stage_reserve(ctx, 9, sizeof(uint64_t) * (FS_DRAWS + 1), &p))) return rc;
     if (!ctx->rng_raw_ok || ctx->rng_raw_seed != state || ctx->rng_raw_dev != p) {
-        uint64_t s = state;
-        for (int k = 0; k < FS_DRAWS; ++k) {
-            s = (uint64_t)(uint32_t)s * 4164903690u + (s >> 32);
-            ctx->rng_raw_host[k] = (uint32_t)s;
-        }
-        VO_HIP_CHECK(hipMemcpyAsync(p, ctx->rng_raw_host, sizeof(uint32_t) * FS_DRAWS, hipMemcpyHostToDevice, ctx->stream));
+        frame_states_from(state, ctx->rng_raw_host);
+        VO_HIP_CHECK(hipMemcpyAsync(p, ctx->rng_raw_host, sizeof(uint64_t) * (FS_DRAWS + 1), hipMemcpyHostToDevice, ctx->stream));
         ctx->rng_raw_seed = state;
         ctx->rng_raw_dev = p;
         ctx->rng_raw_ok = true;
     }
-    *out = (const uint32_t *)p;
+    *out = (const uint64_t *)p;
     return VO_OK;
 }
 
@@ -256,7 +338,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
     const int c0 = max_iters < FS_SAMPLES ? max_iters : FS_SAMPLES;
     const uint64_t state0 = rng_state ? *rng_state : 0xFFFFFFFFFFFFFFFFull;
     int rc;
-    const uint32_t *d_raw;
+    const uint64_t *d_raw;
     if ((rc = frame_raw_draws(ctx, state0, &d_raw))) return rc;
     const bool host = mem == VO_MEM_HOST;
     // One device block: [work | outputs], the outputs contiguous so that one copy takes everything the host reads back
@@ -307,8 +389,8 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
         d_X = (const float *)(hin + o_X);
     }
     if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
-    hipLaunchKernelGGL(frame_prep_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_raw, c0, d_Xc, d_xc,
-                       d_orig, d_meta, d_counts, d_full, d_sub);
+    hipLaunchKernelGGL(frame_prep_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_raw, (size_t)0, c0, d_Xc,
+                       d_xc, d_orig, d_meta, d_counts, d_full, d_sub, (unsigned short *)nullptr, vo_batch_strides());
     VO_HIP_CHECK(hipGetLastError());
     if (n >= 4) {
         if ((rc = vo_p3p_solve(ctx, d_Xc, d_xc, n, K, d_sub, c0, d_Rt, d_valid, VO_MEM_DEVICE))) return rc;
@@ -386,3 +468,300 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
 }
 
 extern "C" int vo_track_pnp_path(const vo_ctx *ctx) { return ctx ? ctx->frame_path : 0; }
+
+// ---------------------------------------------------------------------------
+// The tracked frame of many streams at once: vo_track_pnp for every image pair of two batched pyramids, with one
+// launch chain and one synchronisation for all of them.  Tracker (already batched), then per stream -- one
+// workgroup, or one grid row, each -- the compaction and the sampler, the P3P solves, the scoring, the loop's replay
+// with the winner's mask, and the refit; one copy brings every stream's bookkeeping record, refit and inlier counts
+// to the host, which re-checks each stream's loop as vo_track_pnp does and sends the streams whose loop outlives the
+// first chunk (or whose device-side bookkeeping it cannot vouch for) through vo_solve_pnp_ransac one by one.
+// The first chunk is solved and scored in two stages (FS_STAGE1 samples, then the rest up to the loop's bound after
+// those): clean streams end their loop within a handful of iterations, as OpenCV's does.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void frame_states_kernel(const uint64_t *__restrict__ seeds, int B, uint64_t *__restrict__ states)
+{
+    // one lane per stream: the generator is a serial recurrence (1 536 dependent multiply-adds, ~15 us)
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    uint64_t s = seeds[b];
+    uint64_t *o = states + (size_t)b * (FS_DRAWS + 1);
+    o[0] = s;
+    for (int k = 1; k <= FS_DRAWS; ++k) {
+        s = (uint64_t)(uint32_t)s * 4164903690u + (s >> 32);
+        o[k] = s;
+    }
+}
+
+struct vo_frame_batch {
+    vo_devbuf work, out, states, in_pts, in_X, o_next, o_status, o_full;   // device
+    void *pin = nullptr;            // page-locked: [mirror of `out` | generator seeds]
+    size_t pin_cap = 0;
+    hipEvent_t done = nullptr;
+    bool default_states_ok = false; // `states` holds the one run from OpenCV's initial state
+    const void *default_states_dev = nullptr;
+    // the call between begin and finish
+    bool pending = false;
+    int B = 0, n = 0, c0 = 0, max_iters = 0, refine_iters = 0, mem = 0;
+    double K[9], thr = 0, conf = 0;
+    size_t ws = 0, os = 0, o_Xc = 0, o_xc = 0, o_orig = 0, o_maskc = 0, o_meta = 0, o_ref = 0, o_counts = 0, o_valid = 0;
+    bool has_seeds = false;
+    std::vector<uint64_t> seeds;
+    float *h_next = nullptr;        // the caller's host arrays (VO_MEM_HOST)
+    uint8_t *h_status = nullptr, *h_mask = nullptr;
+    uint8_t *d_full = nullptr;      // inlier masks on the device (the caller's, or o_full)
+};
+
+static int fb_reserve(vo_ctx *ctx, vo_devbuf &b, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.ptr) {
+            VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            VO_HIP_CHECK(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        const size_t cap = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&b.ptr, cap);
+        if (e != hipSuccess) { vo_set_error("device allocation of %zu bytes failed: %s", cap, hipGetErrorString(e)); return VO_ENOMEM; }
+        b.cap = cap;
+    }
+    *out = b.ptr;
+    return VO_OK;
+}
+
+void vo_frame_batch_free(vo_ctx *ctx)
+{
+    vo_frame_batch *fb = ctx->fb;
+    if (!fb) return;
+    for (vo_devbuf *b : {&fb->work, &fb->out, &fb->states, &fb->in_pts, &fb->in_X, &fb->o_next, &fb->o_status, &fb->o_full})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (fb->pin) (void)hipHostFree(fb->pin);
+    if (fb->done) (void)hipEventDestroy(fb->done);
+    delete fb;
+    ctx->fb = nullptr;
+}
+
+extern "C" int vo_track_pnp_batch_begin(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts,
+                                        const float *landmarks, int n, const vo_klt_params *klt, const double *K, double thr,
+                                        double conf, int max_iters, int refine_iters, const uint64_t *rng_state, float *next_pts,
+                                        uint8_t *status, uint8_t *inlier_mask, int mem)
+{
+    VO_REQUIRE(ctx && prev && next && klt && K, "vo_track_pnp_batch: NULL argument");
+    VO_REQUIRE(n >= 1 && prev_pts && landmarks && next_pts && status && inlier_mask, "vo_track_pnp_batch: bad buffers (n=%d)", n);
+    VO_REQUIRE(max_iters >= 1 && max_iters <= (1 << 22) && refine_iters >= 0, "vo_track_pnp_batch: max_iters=%d refine_iters=%d", max_iters, refine_iters);
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_track_pnp_batch: bad mem flag %d", mem);
+    VO_REQUIRE(prev->batch == next->batch && prev->batch >= 1 && prev->batch <= 65535, "vo_track_pnp_batch: pyramids of %d and %d images", prev->batch, next->batch);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->fb) {
+        ctx->fb = new (std::nothrow) vo_frame_batch();
+        if (!ctx->fb) { vo_set_error("vo_track_pnp_batch: out of host memory"); return VO_ENOMEM; }
+        VO_HIP_CHECK(hipEventCreateWithFlags(&ctx->fb->done, hipEventDisableTiming));
+    }
+    vo_frame_batch *fb = ctx->fb;
+    VO_REQUIRE(!fb->pending, "vo_track_pnp_batch_begin: the context's previous batch has not been finished");
+    const int B = prev->batch, c0 = max_iters < FS_SAMPLES ? max_iters : FS_SAMPLES;
+    const size_t cnt = (size_t)B * n;
+    int rc;
+    // one stream's work block and read-back block
+    size_t off = 0;
+    auto take = [&off](size_t bytes, size_t align) { off = (off + align - 1) & ~(align - 1); const size_t o = off; off += bytes; return o; };
+    const size_t o_Xc = take((size_t)n * 12, 256), o_xc = take((size_t)n * 8, 256), o_orig = take((size_t)n * 4, 256),
+                 o_maskc = take((size_t)n, 256), o_sub = take((size_t)c0 * 16, 256), o_Rt = take((size_t)c0 * 96, 256),
+                 o_starts = take((size_t)(c0 + 1) * 2, 256);
+    const size_t ws = (off + 255) & ~(size_t)255;
+    off = 0;
+    const size_t o_meta = take(sizeof(vo_frame_meta), 16), o_ref = take(64, 16), o_counts = take((size_t)c0 * 4 + 4, 16),
+                 o_valid = take((size_t)c0, 16);
+    const size_t os = (off + 255) & ~(size_t)255;
+    void *p;
+    if ((rc = fb_reserve(ctx, fb->work, ws * B, &p))) return rc;
+    char *work = (char *)p;
+    if ((rc = fb_reserve(ctx, fb->out, os * B, &p))) return rc;
+    char *out = (char *)p;
+    const size_t pin_need = os * B + (((size_t)B * 8 + 255) & ~(size_t)255);
+    if (fb->pin_cap < pin_need) {
+        if (fb->pin) {
+            VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            VO_HIP_CHECK(hipHostFree(fb->pin));
+            fb->pin = nullptr;
+            fb->pin_cap = 0;
+        }
+        VO_HIP_CHECK(hipHostMalloc(&fb->pin, pin_need + pin_need / 4, hipHostMallocDefault));
+        fb->pin_cap = pin_need + pin_need / 4;
+    }
+    // generator states: one run for all streams from OpenCV's initial state, or one per stream from the caller's seeds
+    const uint64_t *d_states;
+    size_t states_stride = 0;
+    if (!rng_state) {
+        if ((rc = fb_reserve(ctx, fb->states, sizeof(uint64_t) * (FS_DRAWS + 1), &p))) return rc;
+        if (!fb->default_states_ok || fb->default_states_dev != p) {
+            frame_states_from(0xFFFFFFFFFFFFFFFFull, ctx->rng_raw_host);
+            ctx->rng_raw_ok = false;      // the single-frame call's cache shares the host array
+            VO_HIP_CHECK(hipMemcpyAsync(p, ctx->rng_raw_host, sizeof(uint64_t) * (FS_DRAWS + 1), hipMemcpyHostToDevice, ctx->stream));
+            VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            fb->default_states_ok = true;
+            fb->default_states_dev = p;
+        }
+        d_states = (const uint64_t *)p;
+        fb->has_seeds = false;
+    } else {
+        if ((rc = fb_reserve(ctx, fb->states, sizeof(uint64_t) * (FS_DRAWS + 1) * B, &p))) return rc;
+        fb->default_states_ok = false;
+        uint64_t *pin_seeds = (uint64_t *)((char *)fb->pin + os * B);
+        memcpy(pin_seeds, rng_state, (size_t)B * 8);
+        fb->seeds.assign(rng_state, rng_state + B);
+        fb->has_seeds = true;
+        hipLaunchKernelGGL(frame_states_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, (const uint64_t *)pin_seeds, B, (uint64_t *)p);
+        VO_HIP_CHECK(hipGetLastError());
+        d_states = (const uint64_t *)p;
+        states_stride = FS_DRAWS + 1;
+    }
+    const float *d_pts = prev_pts, *d_X = landmarks;
+    float *d_next = next_pts;
+    uint8_t *d_status = status, *d_full = inlier_mask;
+    if (mem == VO_MEM_HOST) {
+        if ((rc = fb_reserve(ctx, fb->in_pts, cnt * 8, &p))) return rc; d_pts = (const float *)p;
+        if ((rc = fb_reserve(ctx, fb->in_X, cnt * 12, &p))) return rc; d_X = (const float *)p;
+        if ((rc = fb_reserve(ctx, fb->o_next, cnt * 8, &p))) return rc; d_next = (float *)p;
+        if ((rc = fb_reserve(ctx, fb->o_status, cnt, &p))) return rc; d_status = (uint8_t *)p;
+        if ((rc = fb_reserve(ctx, fb->o_full, cnt, &p))) return rc; d_full = (uint8_t *)p;
+        VO_UPLOAD(ctx, d_pts, prev_pts, cnt * 8);
+        VO_UPLOAD(ctx, d_X, landmarks, cnt * 12);
+    }
+    vo_batch_strides bs;
+    bs.count = B; bs.work = ws; bs.out = os; bs.mask = (size_t)n;
+    float *d_Xc = (float *)(work + o_Xc), *d_xc = (float *)(work + o_xc);
+    int *d_orig = (int *)(work + o_orig), *d_sub = (int *)(work + o_sub), *d_counts = (int *)(out + o_counts);
+    uint8_t *d_valid = (uint8_t *)(out + o_valid);
+    unsigned short *d_starts = (unsigned short *)(work + o_starts);
+    vo_frame_meta *d_meta = (vo_frame_meta *)(out + o_meta);
+    double *d_Rt = (double *)(work + o_Rt), *d_ref = (double *)(out + o_ref);
+    if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
+    hipLaunchKernelGGL(frame_prep_kernel, dim3(B), dim3(FS_THREADS), 0, ctx->stream, (const uint8_t *)d_status, d_X, (const float *)d_next, n,
+                       d_states, states_stride, c0, d_Xc, d_xc, d_orig, d_meta, d_counts, d_full, d_sub, d_starts, bs);
+    VO_HIP_CHECK(hipGetLastError());
+    // VO_FRAME_STAGE1 in the environment moves the first stage's size (0 or >= the chunk: one stage; comparison runs)
+    const char *stage1_env = getenv("VO_FRAME_STAGE1");
+    const int stage1 = stage1_env ? atoi(stage1_env) : FS_STAGE1;
+    const int c1 = stage1 > 0 && stage1 < c0 ? stage1 : c0;
+    if ((rc = vo_p3p_solve_dev(ctx, d_Xc, d_xc, n, K, d_sub, c1, d_Rt, d_valid, bs))) return rc;
+    if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c1, nullptr, thr, d_counts, nullptr, true, bs))) return rc;
+    if (c1 < c0) {
+        hipLaunchKernelGGL(frame_bound_kernel, dim3(B), dim3(64), 0, ctx->stream, (const int *)d_counts, (const uint8_t *)d_valid, c1, max_iters,
+                           conf, d_meta, bs);
+        VO_HIP_CHECK(hipGetLastError());
+        if ((rc = vo_p3p_solve_dev(ctx, d_Xc, d_xc, n, K, d_sub, c0, d_Rt, d_valid, bs, c1, &d_meta->bound0))) return rc;
+        if ((rc = vo_score_pnp_dev(ctx, d_Xc, d_xc, n, &d_meta->m, K, d_Rt, c0, nullptr, thr, d_counts, nullptr, true, bs, c1, &d_meta->bound0)))
+            return rc;
+    }
+    if ((rc = vo_pnp_first_chunk_tail(ctx, d_Xc, d_xc, n, -1, d_orig, d_counts, d_valid, c0, max_iters, conf, K, thr, d_Rt, d_meta, nullptr,
+                                      nullptr, d_full, refine_iters, d_ref, bs, d_starts, d_states, states_stride)))
+        return rc;
+    if ((rc = vo_download_async(ctx, fb->pin, out, os * B))) return rc;
+    VO_HIP_CHECK(hipEventRecord(fb->done, ctx->stream));
+    fb->pending = true;
+    fb->B = B; fb->n = n; fb->c0 = c0; fb->max_iters = max_iters; fb->refine_iters = refine_iters; fb->mem = mem;
+    memcpy(fb->K, K, sizeof(fb->K));
+    fb->thr = thr; fb->conf = conf;
+    fb->ws = ws; fb->os = os; fb->o_Xc = o_Xc; fb->o_xc = o_xc; fb->o_orig = o_orig; fb->o_maskc = o_maskc;
+    fb->o_meta = o_meta; fb->o_ref = o_ref; fb->o_counts = o_counts; fb->o_valid = o_valid;
+    fb->h_next = next_pts; fb->h_status = status; fb->h_mask = inlier_mask;
+    fb->d_full = d_full;
+    return VO_OK;
+}
+
+extern "C" int vo_track_pnp_batch_finish(vo_ctx *ctx, uint64_t *rng_state, double *Rt_out, int32_t *n_tracked, int32_t *n_inliers,
+                                         int32_t *path)
+{
+    VO_REQUIRE(ctx && Rt_out && n_tracked && n_inliers, "vo_track_pnp_batch_finish: NULL argument");
+    vo_frame_batch *fb = ctx->fb;
+    VO_REQUIRE(fb && fb->pending, "vo_track_pnp_batch_finish: no batch was begun on this context");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    fb->pending = false;
+    VO_HIP_CHECK(hipEventSynchronize(fb->done));
+    const int B = fb->B, n = fb->n, c0 = fb->c0, max_iters = fb->max_iters;
+    const char *hout = (const char *)fb->pin;
+    std::vector<int> slow;
+    for (int b = 0; b < B; ++b) {
+        const char *hb_ = hout + (size_t)b * fb->os;
+        const vo_frame_meta meta = *(const vo_frame_meta *)(hb_ + fb->o_meta);
+        const double *h_ref = (const double *)(hb_ + fb->o_ref);
+        const int m = meta.m;
+        n_tracked[b] = m;
+        n_inliers[b] = 0;
+        if (path) path[b] = 0;
+        if (rng_state && fb->has_seeds) rng_state[b] = fb->seeds[b];
+        else if (rng_state) rng_state[b] = 0xFFFFFFFFFFFFFFFFull;
+        if (m < 4 || n < 4) continue;        // the masks were cleared by the preparation kernel
+        int hb, hbc, hn;
+        vo_ransac_replay_first_chunk((const int32_t *)(hb_ + fb->o_counts), (const uint8_t *)(hb_ + fb->o_valid), c0, m, 4, fb->conf, max_iters,
+                                     &hb, &hbc, &hn);
+        const bool finished = hn <= c0 || c0 >= max_iters;
+        const bool agree = !meta.overflow && hbc == meta.win && hn == meta.niters && (hbc < 0 || hb == meta.best);
+        if (!(finished && agree)) {
+            if (path) path[b] = !agree ? 3 : 2;
+            slow.push_back(b);
+            continue;
+        }
+        if (path) path[b] = 1;
+        if (rng_state) rng_state[b] = meta.state;
+        if (hbc < 0) continue;
+        double *Rt = Rt_out + 12 * (size_t)b;
+        memcpy(Rt, meta.Rt, sizeof(meta.Rt));
+        if (fb->refine_iters > 0) {
+            bool finite = true;
+            for (int k = 0; k < 6; ++k) finite = finite && isfinite(h_ref[k]);
+            if (finite) {
+                double R[9];
+                frame_matrix_from_rotvec(h_ref, R);
+                for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt[4 * r + c] = R[3 * r + c]; Rt[4 * r + 3] = h_ref[3 + r]; }
+            }
+        }
+        n_inliers[b] = hb;
+    }
+    // streams whose loop wants more samples than the first chunk (or whose device-side bookkeeping the host cannot
+    // vouch for): the whole RANSAC call on the stream's survivors, which are already on the device
+    int rc;
+    for (int b : slow) {
+        char *wb = (char *)fb->work.ptr + (size_t)b * fb->ws;
+        const int m = n_tracked[b];
+        uint64_t st = fb->has_seeds ? fb->seeds[b] : 0xFFFFFFFFFFFFFFFFull;
+        int32_t good = 0;
+        uint8_t *d_maskc = (uint8_t *)(wb + fb->o_maskc), *d_full = fb->d_full + (size_t)b * n;
+        if ((rc = vo_solve_pnp_ransac(ctx, (const float *)(wb + fb->o_Xc), (const float *)(wb + fb->o_xc), m, fb->K, fb->thr, fb->conf, max_iters,
+                                      fb->refine_iters, &st, Rt_out + 12 * (size_t)b, d_maskc, &good, VO_MEM_DEVICE)))
+            return rc;
+        n_inliers[b] = good;
+        if (rng_state) rng_state[b] = st;
+        VO_HIP_CHECK(hipMemsetAsync(d_full, 0, (size_t)n, ctx->stream));
+        if (good > 0) {
+            hipLaunchKernelGGL(frame_scatter_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const int *)(wb + fb->o_orig),
+                               (const uint8_t *)d_maskc, m, d_full);
+            VO_HIP_CHECK(hipGetLastError());
+        }
+    }
+    if (fb->mem == VO_MEM_HOST) {
+        const size_t cnt = (size_t)B * n;
+        VO_HIP_CHECK(hipMemcpyAsync(fb->h_next, fb->o_next.ptr, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(fb->h_status, fb->o_status.ptr, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipMemcpyAsync(fb->h_mask, fb->o_full.ptr, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } else if (!slow.empty()) {
+        VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_track_pnp_batch(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, const float *landmarks,
+                                  int n, const vo_klt_params *klt, const double *K, double thr, double conf, int max_iters,
+                                  int refine_iters, uint64_t *rng_state, float *next_pts, uint8_t *status, double *Rt_out,
+                                  uint8_t *inlier_mask, int32_t *n_tracked, int32_t *n_inliers, int32_t *path, int mem)
+{
+    VO_REQUIRE(Rt_out && n_tracked && n_inliers, "vo_track_pnp_batch: NULL argument");
+    int rc = vo_track_pnp_batch_begin(ctx, prev, next, prev_pts, landmarks, n, klt, K, thr, conf, max_iters, refine_iters, rng_state, next_pts,
+                                      status, inlier_mask, mem);
+    if (rc) return rc;
+    return vo_track_pnp_batch_finish(ctx, rng_state, Rt_out, n_tracked, n_inliers, path);
+}

@@ -38,11 +38,12 @@ struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    vo_devbuf stage[10];         // 0-7: staging of host-side arguments; 8, 9: vo_track_pnp's block and raw generator draws
+    vo_devbuf stage[10];         // 0-7: staging of host-side arguments; 8, 9: vo_track_pnp's block and generator states
     void *pinned = nullptr;      // page-locked host buffer for small read-backs (a copy into pageable memory blocks the caller)
     size_t pinned_cap = 0;
-    // cv::RNG raw outputs that stage[9] holds (vo_track_pnp draws its first samples on the device)
-    uint32_t rng_raw_host[1536];
+    // cv::RNG states that stage[9] holds (vo_track_pnp draws its first samples on the device): entry p is the state
+    // after p draws, a draw is the low half of the state after it
+    uint64_t rng_raw_host[1537];
     uint64_t rng_raw_seed = 0;
     const void *rng_raw_dev = nullptr;
     bool rng_raw_ok = false;
@@ -58,7 +59,12 @@ struct vo_ctx {
     // device pool of the last destroyed bundle-adjustment solver, handed to the next one that fits (vo_ba_create)
     char *ba_pool = nullptr;
     size_t ba_pool_bytes = 0;
+    // device and page-locked state of vo_track_pnp_batch (vo_frame.hip), kept from call to call
+    struct vo_frame_batch *fb = nullptr;
 };
+
+// vo_frame.hip: frees what ctx->fb holds (vo_ctx_destroy)
+void vo_frame_batch_free(vo_ctx *ctx);
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
 
@@ -140,12 +146,28 @@ void vo_results_abandon(vo_ctx *ctx);      // forget the noted regions (a call t
 // Make stage[slot] at least `bytes` large; returns its device pointer in *out.
 int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out);
 
+// Several independent problems of one shape in one launch (the streams of vo_track_pnp_batch): problem b's arrays
+// start `work` bytes (points, subsets, candidate models, row maps), `out` bytes (counts, validity flags, the
+// bookkeeping record and the refit's result) or `mask` bytes (the caller's inlier mask) after problem b-1's.
+// count = 1 with zero strides is the single problem every other caller has.
+struct vo_batch_strides {
+    int count = 1;
+    size_t work = 0, out = 0, mask = 0;
+};
+
 // vo_score.hip: vo_score_pnp on device pointers whose point count (*n_dev <= n_cap) and, optionally, first model
 // (*first_dev; negative: nothing to do) are known only on the device; counts_cleared: dcounts is already zero.
-// Asynchronous.
+// hyp_lo_dev (optional): candidates below *hyp_lo_dev are left alone -- and, with skip_bound_dev, candidates from
+// *skip_bound_dev + 1 on as well (the RANSAC loop cannot reach them any more).  Asynchronous.
 int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
                      const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks,
-                     bool counts_cleared);
+                     bool counts_cleared, const vo_batch_strides &bs = vo_batch_strides(), int hyp_lo = 0,
+                     const int *skip_bound_dev = nullptr);
+// vo_solvers.hip: vo_p3p_solve on device pointers, for bs.count problems; samples below samp_lo are left alone, and
+// with skip_bound_dev those from *skip_bound_dev + 1 on as well.  Asynchronous.
+int vo_p3p_solve_dev(vo_ctx *ctx, const float *dX, const float *dx, int n, const double *K, const int32_t *dsub, int S,
+                     double *dRt, uint8_t *dvalid, const vo_batch_strides &bs, int samp_lo = 0,
+                     const int *skip_bound_dev = nullptr);
 
 // vo_ba.hip: pose refits on device pointers; both enqueue the copy of {pose (6), cost, iterations} into host_out
 // and do not synchronise.  The second starts from [R|t] number sel (or *sel_dev) of dRt, with the number of
@@ -155,7 +177,8 @@ int vo_refine_pose_async(vo_ctx *ctx, const float *dX, const float *dx, int n, c
                          const double *pose_in, int max_iters, double *host_out);
 int vo_refine_pose_from_Rt_async(vo_ctx *ctx, const float *dX, const float *dx, int n, const int *n_dev, const uint8_t *dmask,
                                  const int *mask_row, const double *K, const double *dRt, int sel, const int *sel_dev,
-                                 int max_iters, double *host_out, double *d_out);
+                                 int max_iters, double *host_out, double *d_out,
+                                 const vo_batch_strides &bs = vo_batch_strides());
 
 // What the device-side RANSAC bookkeeping of a first chunk of PnP samples leaves behind (vo_frame.hip).
 struct vo_frame_meta {
@@ -164,7 +187,8 @@ struct vo_frame_meta {
     int best;         // its inlier count
     int niters;       // the loop's iteration bound after the first chunk
     int overflow;     // vo_track_pnp: the raw draws did not suffice for the chunk's subsets
-    int pad[3];
+    int bound0;       // staged first chunk: the loop's iteration bound after the first stage's candidates
+    uint64_t state;   // the generator after the iterations the loop ran (when it ended inside the chunk)
     double Rt[12];    // the winner
 };
 // vo_frame.hip: after the c0 candidates dRt (validity dvalid) have been scored into dcounts -- replay of OpenCV's loop
@@ -176,7 +200,8 @@ struct vo_frame_meta {
 int vo_pnp_first_chunk_tail(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, int m_host, const int *row,
                             const int32_t *dcounts, const uint8_t *dvalid, int c0, int max_iters, double conf, const double *K,
                             double thr, const double *dRt, vo_frame_meta *d_meta, int32_t *out_counts, uint8_t *out_valid,
-                            uint8_t *d_mask, int refine_iters, double *d_ref);
+                            uint8_t *d_mask, int refine_iters, double *d_ref, const vo_batch_strides &bs = vo_batch_strides(),
+                            const unsigned short *d_starts = nullptr, const uint64_t *d_states = nullptr, size_t states_stride = 0);
 
 // vo_pyramid.hip: one host image into a one-image pyramid through page-locked memory the caller provides (w * h
 // bytes, untouched until the stream has run the copy); does not wait for the device.

@@ -21,13 +21,26 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
                                                               int n, const double *__restrict__ models, int H,
                                                               double fx, double fy, double cx, double cy, float t,
                                                               int *__restrict__ counts, uint8_t *__restrict__ masks,
-                                                              const int *__restrict__ n_dev, const int *__restrict__ first_dev)
+                                                              const int *__restrict__ n_dev, const int *__restrict__ first_dev,
+                                                              vo_batch_strides bs, int hyp_lo, const int *__restrict__ skip_bound)
 {
     // n_dev / first_dev (optional): the point count and the index of the first model live on the device, left there
-    // by earlier kernels of the same stream (a negative first model: nothing to score)
+    // by earlier kernels of the same stream (a negative first model: nothing to score).
+    // blockIdx.z: the problem (a stream of a batched frame), whose arrays start bs.work / bs.out bytes after the
+    // problem before.  Candidates below hyp_lo are another launch's; with skip_bound, candidates beyond *skip_bound
+    // (the RANSAC loop's iteration bound after an earlier stage, which only shrinks) keep their cleared count.
     const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * SC_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = hyp_lo + blockIdx.x * SC_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (h >= H) return;
+    if (bs.count > 1 || skip_bound) {
+        const size_t b = blockIdx.z;
+        pa = (const float *)((const char *)pa + b * bs.work);
+        pb = (const float *)((const char *)pb + b * bs.work);
+        models = (const double *)((const char *)models + b * bs.work);
+        counts = (int *)((char *)counts + b * bs.out);
+        if (n_dev) n_dev = (const int *)((const char *)n_dev + b * bs.out);
+        if (skip_bound && h > *(const int *)((const char *)skip_bound + b * bs.out)) return;
+    }
     if (n_dev) n = *n_dev;
     int64_t first = 0;
     if (first_dev) {
@@ -40,6 +53,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
     for (int k = 0; k < MS; ++k) m[k] = models[(first + h) * MS + k];
     const int i0 = blockIdx.y * SC_CHUNK;
     const int i1 = min(n, i0 + SC_CHUNK);
+    if (i0 >= n && gridDim.y > 1) return;       // a chunk beyond a device-side point count adds nothing
     int good = 0;
     for (int i = i0 + lane; i < i1; i += 64) {
         bool in;
@@ -110,7 +124,8 @@ static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, co
     if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(d_c, 0, (size_t)H * 4, ctx->stream));
     dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
     hipLaunchKernelGGL(score_kernel<PNP>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, d_pa, d_pb, n, d_m, H, Kh[0], Kh[4],
-                       Kh[2], Kh[5], t, d_c, d_k, (const int *)nullptr, (const int *)nullptr);
+                       Kh[2], Kh[5], t, d_c, d_k, (const int *)nullptr, (const int *)nullptr, vo_batch_strides(), 0,
+                       (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_RESULT(ctx, counts, d_c, (size_t)H * 4);
@@ -135,19 +150,21 @@ extern "C" int vo_score_pnp(vo_ctx *ctx, const float *X, const float *x, int n, 
 // vo_score_pnp on device pointers whose point count (and, optionally, first model) is only known on the device:
 // n_cap bounds the count for the launch geometry, *n_dev is the count, models + 12 * *first_dev the first model;
 // counts_cleared: an earlier kernel has zeroed dcounts (needed when the points span several workgroups, which
-// add up their shares).  Asynchronous on the context's stream.
+// add up their shares).  bs: several problems of this shape in one launch.  Candidates hyp_lo .. H-1 are scored,
+// those beyond *skip_bound_dev left alone.  Asynchronous on the context's stream.
 int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, const int *n_dev, const double *K,
                      const double *dRt, int H, const int *first_dev, double thr, int32_t *dcounts, uint8_t *dmasks,
-                     bool counts_cleared)
+                     bool counts_cleared, const vo_batch_strides &bs, int hyp_lo, const int *skip_bound_dev)
 {
-    if (H == 0) return VO_OK;
+    if (H <= hyp_lo || bs.count <= 0) return VO_OK;
     const int chunks = n_cap > 0 ? (n_cap + SC_CHUNK - 1) / SC_CHUNK : 1;
-    VO_REQUIRE(chunks <= 65535, "vo_score_pnp: n=%d exceeds %d points", n_cap, 65535 * SC_CHUNK);
+    VO_REQUIRE(chunks <= 65535 && bs.count <= 65535, "vo_score_pnp: n=%d exceeds %d points (or %d problems)", n_cap, 65535 * SC_CHUNK, bs.count);
+    VO_REQUIRE(bs.count == 1 || (counts_cleared && !dmasks && !first_dev), "vo_score_pnp: batched scoring wants cleared counts and no masks");
     if (chunks > 1 && !counts_cleared) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)H * 4, ctx->stream));
     const float t = (float)(thr * thr);
-    dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
+    dim3 grid((H - hyp_lo + SC_WAVES - 1) / SC_WAVES, chunks, bs.count);
     hipLaunchKernelGGL(score_kernel<true>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, dX, dx, n_cap, dRt, H, K[0], K[4], K[2],
-                       K[5], t, dcounts, dmasks, n_dev, first_dev);
+                       K[5], t, dcounts, dmasks, n_dev, first_dev, bs, hyp_lo, skip_bound_dev);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }

@@ -125,12 +125,28 @@ struct K9 { double k[9]; };
 
 // subsets: (S,4) int32 indices into X/x.  Rt: (S,12) [R|t] of the best of the <= 4
 // P3P solutions of points 0..2 as judged by point 3; valid: (S) 1 if one exists.
+// blockIdx.y: the problem (a stream of a batched frame), whose arrays start bs.work / bs.out bytes after the problem
+// before.  Samples below samp_lo are another launch's; with skip_bound, samples beyond *skip_bound (the RANSAC loop's
+// iteration bound after an earlier stage, which only shrinks) are marked invalid unsolved.
 __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__restrict__ X, const float *__restrict__ x, int n,
                                                             K9 K, K9 Kinv, const int *__restrict__ subsets, int S,
-                                                            double *__restrict__ Rt, uint8_t *__restrict__ valid)
+                                                            double *__restrict__ Rt, uint8_t *__restrict__ valid,
+                                                            vo_batch_strides bs, int samp_lo, const int *__restrict__ skip_bound)
 {
-    const int s = blockIdx.x * SOLVER_THREADS + threadIdx.x;
+    const int s = samp_lo + blockIdx.x * SOLVER_THREADS + threadIdx.x;
     if (s >= S) return;
+    {
+        const size_t b = blockIdx.y;
+        X = (const float *)((const char *)X + b * bs.work);
+        x = (const float *)((const char *)x + b * bs.work);
+        subsets = (const int *)((const char *)subsets + b * bs.work);
+        Rt = (double *)((char *)Rt + b * bs.work);
+        valid += b * bs.out;
+        if (skip_bound) {
+            skip_bound = (const int *)((const char *)skip_bound + b * bs.out);
+            if (s > *skip_bound) { valid[s] = 0; return; }
+        }
+    }
     double P[4][3], j[3][3], obs3[2];
     bool ok = true;
     for (int k = 0; k < 4; ++k) {
@@ -345,13 +361,27 @@ extern "C" int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, 
         VO_UPLOAD(ctx, (void *)d_sub, subsets, (size_t)S * 16);
     }
     hipLaunchKernelGGL(p3p_kernel, dim3((S + SOLVER_THREADS - 1) / SOLVER_THREADS), dim3(SOLVER_THREADS), 0, ctx->stream, d_X,
-                       d_x, n, Kv, Ki, d_sub, S, d_Rt, d_valid);
+                       d_x, n, Kv, Ki, d_sub, S, d_Rt, d_valid, vo_batch_strides(), 0, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_RESULT(ctx, Rt, d_Rt, (size_t)S * 96);
         VO_RESULT(ctx, valid, d_valid, (size_t)S);
         VO_RESULTS_FINISH(ctx);
     }
+    return VO_OK;
+}
+
+int vo_p3p_solve_dev(vo_ctx *ctx, const float *dX, const float *dx, int n, const double *K, const int32_t *dsub, int S,
+                     double *dRt, uint8_t *dvalid, const vo_batch_strides &bs, int samp_lo, const int *skip_bound_dev)
+{
+    if (S <= samp_lo || bs.count <= 0) return VO_OK;
+    K9 Kv, Ki;
+    memcpy(Kv.k, K, sizeof(Kv.k));
+    VO_REQUIRE(invert3(K, Ki.k), "vo_p3p_solve: K is singular");
+    VO_REQUIRE(bs.count <= 65535, "vo_p3p_solve: %d problems in one launch", bs.count);
+    hipLaunchKernelGGL(p3p_kernel, dim3((S - samp_lo + SOLVER_THREADS - 1) / SOLVER_THREADS, bs.count), dim3(SOLVER_THREADS), 0,
+                       ctx->stream, dX, dx, n, Kv, Ki, dsub, S, dRt, dvalid, bs, samp_lo, skip_bound_dev);
+    VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
 

@@ -960,6 +960,80 @@ def track_pnp_path(ctx: Context) -> int:
     return int(ctx.lib.vo_track_pnp_path(ctx.handle))
 
 
+class TrackPnpBatch:
+    """The tracked frame of many streams in one launch chain (vo_track_pnp_batch): stream b tracks image b of `prev`
+    into image b of `nxt`, filters by status and runs PnP-RANSAC with its refit on the survivors.
+
+    begin(...) enqueues the chain and returns; finish() waits once, re-checks every stream's loop on the host and
+    returns (next_pts (B,n,2), status (B,n), Rt (B,3,4) f64, inlier mask (B,n), tracked (B,) i32, inliers (B,) i32
+    -- 0: no pose, that stream's Rt row is zero --, rng states after the draws (B,) u64, path (B,) i32).  numpy or
+    torch, as the points are; with torch the three arrays stay on the GPU.  One batch per context in flight."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._out = None
+
+    def begin(self, prev: Pyramid, nxt: Pyramid, pts, landmarks, K, thr: float, conf: float, max_iters: int,
+              refine_iters: int = 10, klt_max_iters: int = 10, klt_eps: float = 0.001, klt_min_eig: float = 1e-2,
+              rng_state=None, out=None) -> "TrackPnpBatch":
+        Kh = _k_host(K)
+        prm = KltParams(int(klt_max_iters), float(klt_eps), float(klt_min_eig))
+        B = prev.batch
+        if nxt.batch != B:
+            raise ValueError("track_pnp_batch: pyramids of different batch sizes")
+        if _is_torch(pts):
+            import torch
+            p = _device_points(pts, B, "track_pnp_batch: pts")
+            X = landmarks
+            if not (_is_torch(X) and X.is_cuda and X.dtype == torch.float32):
+                raise ValueError("track_pnp_batch: landmarks must be a float32 GPU tensor like pts")
+            X = X.reshape(B, -1, 3).contiguous()
+            n = int(p.shape[1])
+            if out is None:
+                out = (torch.empty_like(p), torch.empty((B, n), dtype=torch.uint8, device=p.device),
+                       torch.empty((B, n), dtype=torch.uint8, device=p.device))
+            for t, dt, shape, what in ((out[0], torch.float32, (B, n, 2), "next_pts"), (out[1], torch.uint8, (B, n), "status"),
+                                       (out[2], torch.uint8, (B, n), "inlier mask")):
+                if not (_is_torch(t) and t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()):
+                    raise ValueError(f"track_pnp_batch: out {what} must be a contiguous {dt} GPU tensor of shape {shape}")
+            mem = VO_MEM_DEVICE
+        else:
+            p = np.ascontiguousarray(pts, np.float32).reshape(B, -1, 2)
+            X = np.ascontiguousarray(landmarks, np.float32).reshape(B, -1, 3)
+            n = int(p.shape[1])
+            out = (np.zeros_like(p), np.zeros((B, n), np.uint8), np.zeros((B, n), np.uint8))
+            mem = VO_MEM_HOST
+        if int(X.shape[1]) != n:
+            raise ValueError("track_pnp_batch: pts and landmarks differ in length")
+        states = None
+        if rng_state is not None:
+            states = np.ascontiguousarray(rng_state, np.uint64).reshape(B)
+        check(self.ctx.lib.vo_track_pnp_batch_begin(self.ctx.handle, prev.handle, nxt.handle, _ptr(p), _ptr(X), n, ctypes.byref(prm),
+                                                    Kh.ctypes.data_as(_lib.c_f64p), float(thr), float(conf), int(max_iters),
+                                                    int(refine_iters), _ptr(states), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), mem),
+              "vo_track_pnp_batch_begin")
+        self._out = (out, B, (p, X, states))      # inputs kept alive until finish
+        return self
+
+    def finish(self):
+        if self._out is None:
+            raise RuntimeError("track_pnp_batch: finish without begin")
+        out, B, _ = self._out
+        self._out = None
+        Rt = np.zeros((B, 3, 4))
+        tracked, good, path = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        states = np.zeros(B, np.uint64)
+        check(self.ctx.lib.vo_track_pnp_batch_finish(self.ctx.handle, _ptr(states), Rt.ctypes.data_as(_lib.c_f64p), _ptr(tracked),
+                                                     _ptr(good), _ptr(path)), "vo_track_pnp_batch_finish")
+        return out[0], out[1], Rt, out[2], tracked, good, states, path
+
+
+def track_pnp_batch(ctx: Context, prev: Pyramid, nxt: Pyramid, pts, landmarks, K, thr: float, conf: float, max_iters: int,
+                    **kw):
+    """begin + finish of TrackPnpBatch in one call (one synchronisation for all streams)."""
+    return TrackPnpBatch(ctx).begin(prev, nxt, pts, landmarks, K, thr, conf, max_iters, **kw).finish()
+
+
 def find_fundamental_ransac(ctx: Context, m1, m2, thr: float, conf: float, max_iters: int, rng_state: Optional[int] = None):
     """Whole fundamental-matrix RANSAC call (7-point candidates, OpenCV's loop replayed, no refit) ->
     (F (3,3) f64 or None, inlier mask (n,) u8, number of inliers, rng state after the draws).  Host arrays."""
