@@ -381,6 +381,13 @@ int vo_track_pnp_batch_begin(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next
 int vo_track_pnp_batch_finish(vo_ctx *ctx, uint64_t *rng_state, double *Rt_out, int32_t *n_tracked, int32_t *n_inliers,
                               int32_t *path);
 
+/* Measurement aid (no counterpart in the reference): while enabled, vo_track_pnp_batch_begin brackets its tracker
+ * launch with a HIP event pair on the context's stream; vo_profile_tracker_ms waits for the pair of the last such
+ * begin and returns the launch's duration.  An event pair costs a few microseconds of idle queue: benchmarks enable
+ * it for a fraction of their steps. */
+int vo_profile_tracker(vo_ctx *ctx, int enable);
+int vo_profile_tracker_ms(vo_ctx *ctx, float *ms);
+
 /* ---- corner mask and sub-pixel refinement of FeatureExtractor.harris -------------------------
  * vo_harris_mask replaces cv.cornerHarris + cv.dilate + cv.threshold + np.uint8
  * (vo_pipeline/featureExtraction.py:40-43): mask = 255 where the 3x3 maximum of the response

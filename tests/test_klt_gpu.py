@@ -208,7 +208,7 @@ def test_bench_workload_parity(oracle, ctx):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     distinct = 8                                             # eight seeded streams, repeated to fill the launch
-    frames, pts = bench.make_streams(list(range(distinct)), 2)
+    frames, pts, _ = bench.make_streams(list(range(distinct)), 2)
     S = 64
     f = np.tile(frames, (1, S // distinct, 1, 1))
     p = np.tile(pts, (S // distinct, 1, 1))
@@ -284,7 +284,7 @@ def test_klt_translation_equivariance_full_size(ctx, klt_kernel):
     from visual_odometry_amd import hip
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    frames, _ = bench.make_streams([5], 2)
+    frames, _, _ = bench.make_streams([5], 2)
     img0, img1 = frames[0, 0], frames[1, 0]
     dy, dx = 16, 24                                   # multiples of 2^3
     H, W = img0.shape

@@ -28,7 +28,7 @@ def main():
     S, G, R = a.streams, a.groups, 3
     assert S % G == 0
     Sg = S // G
-    f0, p0 = bench.make_streams(list(range(a.distinct)), R)
+    f0, p0, _ = bench.make_streams(list(range(a.distinct)), R)
     rep = (S + a.distinct - 1) // a.distinct
     frames = torch.from_numpy(np.tile(f0, (1, rep, 1, 1))[:, :S].copy()).to(dev)
     pts = torch.from_numpy(np.tile(p0, (rep, 1, 1))[:S].copy()).to(dev)

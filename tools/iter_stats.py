@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--max-level", type=int, default=bench.MAX_LEVEL)
     a = ap.parse_args()
-    frames, pts = bench.make_streams(list(range(a.streams)), 3)
+    frames, pts, _ = bench.make_streams(list(range(a.streams)), 3)
     L = oracle.lib()
     L.vo_or_klt_set_iter_log.argtypes = [ctypes.c_void_p]
     per_kp, per_wave, levels_run = [], [], 0

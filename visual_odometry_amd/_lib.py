@@ -91,6 +91,8 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_f64p, c_vp, c_vp, c_vp, c_vp, ctypes.c_int]),
     "vo_track_pnp_batch_begin": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_f64p, ctypes.c_double,
                                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_int]),
+    "vo_profile_tracker": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "vo_profile_tracker_ms": (ctypes.c_int, [c_vp, c_f32p]),
     "vo_track_pnp_batch_finish": (ctypes.c_int, [c_vp, c_vp, c_f64p, c_vp, c_vp, c_vp]),
     "vo_find_fundamental_ransac": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                                   ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), c_f64p, c_vp,

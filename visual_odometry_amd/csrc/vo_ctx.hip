@@ -80,6 +80,8 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->res_area) (void)hipHostFree(ctx->res_area);
+    if (ctx->prof0) (void)hipEventDestroy(ctx->prof0);
+    if (ctx->prof1) (void)hipEventDestroy(ctx->prof1);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -106,6 +108,27 @@ extern "C" int vo_timer_stop_ms(vo_ctx *ctx, float *ms)
     VO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
     VO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     VO_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VO_OK;
+}
+
+extern "C" int vo_profile_tracker(vo_ctx *ctx, int enable)
+{
+    VO_REQUIRE(ctx != nullptr, "vo_profile_tracker: ctx is NULL");
+    if (enable && !ctx->prof0) {
+        VO_HIP_CHECK(hipSetDevice(ctx->device));
+        VO_HIP_CHECK(hipEventCreate(&ctx->prof0));
+        VO_HIP_CHECK(hipEventCreate(&ctx->prof1));
+    }
+    ctx->prof_tracker = enable != 0;
+    return VO_OK;
+}
+
+extern "C" int vo_profile_tracker_ms(vo_ctx *ctx, float *ms)
+{
+    VO_REQUIRE(ctx && ms, "vo_profile_tracker_ms: NULL argument");
+    if (!ctx->prof_recorded) { vo_set_error("vo_profile_tracker_ms: no tracker launch was timed on this context"); return VO_ESTATE; }
+    VO_HIP_CHECK(hipEventSynchronize(ctx->prof1));
+    VO_HIP_CHECK(hipEventElapsedTime(ms, ctx->prof0, ctx->prof1));
     return VO_OK;
 }
 

@@ -19,20 +19,20 @@
 #include <new>
 #include <vector>
 
-#define FS_THREADS 1024
+#define FS_THREADS 256
 #define FS_SAMPLES 256                      // samples of the first chunk
 #define FS_DRAWS (4 * FS_SAMPLES + 512)     // raw generator outputs kept on the device: room for 512 rejected draws
 #define FS_STAGE1 32                        // batched frames: samples solved and scored before the loop's bound is looked at
 
-// One subset of four distinct indices drawn from position p of the raw generator output, as
-// RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another draw.
-// Returns the position after the subset; FS_DRAWS when the draws ran out (a subset whose last draw is the
+// One subset of four distinct indices drawn from position p of the generator's output (draw p = the low half of
+// states[p + 1]), as RANSACPointSetRegistrator::getSubset does: index = draw % count, a repeated index costs another
+// draw.  Returns the position after the subset; FS_DRAWS when the draws ran out (a subset whose last draw is the
 // buffer's last entry counts as ran out too, which keeps the two cases apart at no cost but one subset).
-__device__ static inline int frame_draw_subset(const uint32_t *raw, int p, uint32_t m, int *idx)
+__device__ static inline int frame_draw_subset(const uint64_t *__restrict__ states, int p, uint32_t m, int *idx)
 {
     int have = 0;
     while (have < 4 && p < FS_DRAWS) {
-        const int j = (int)(raw[p++] % m);
+        const int j = (int)((uint32_t)states[++p] % m);
         bool dup = false;
         for (int k = 0; k < have; ++k) dup = dup || idx[k] == j;
         if (!dup) idx[have++] = j;
@@ -44,10 +44,13 @@ __device__ static inline int frame_draw_subset(const uint32_t *raw, int p, uint3
 // one stream):
 //  * rows with status 1 are compacted in order (landmarks and tracked points side by side; orig[j] = input row of
 //    survivor j), the full-length inlier mask and the candidates' inlier counts are cleared;
-//  * subsets 0 .. c0-1 are drawn.  Where subset i starts depends on the rejections before it; "the position after
-//    the subset that starts at p" is a function of p alone, so the starts are the orbit of 0 under it: every position
-//    computes its successor, log2(c0) rounds of pointer doubling give hops of 1, 2, 4, ... subsets, and sample i
-//    combines the hops of its set bits.
+//  * subsets 0 .. c0-1 are drawn by the first wavefront.  Where subset i starts depends on the rejected draws
+//    before it, and those are rare (a draw repeats one of up to three earlier indices out of m): lane l assumes that
+//    the next 64 subsets start four draws apart and tests its own four draws; the subsets before the first lane
+//    that met a repeated index stand, that lane's subset is drawn the long way, and the wavefront goes on behind it.
+//    With thousands of survivors a round settles 64 subsets; with a handful it settles one or two.
+// The kernel uses no LDS to speak of and four wavefronts, so that its workgroups find room on compute units that a
+// tracker launch of another stream group keeps busy.
 // states: the generator's state after 0, 1, ..., FS_DRAWS draws (a draw is the low half of the state after it);
 // stream b reads its own run of them, states_stride entries after stream b-1's (0: all streams draw alike).
 // starts (optional, c0 + 1 entries): how many draws precede subset i.
@@ -59,9 +62,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
                                                                 uint8_t *__restrict__ full, int *__restrict__ subsets,
                                                                 unsigned short *__restrict__ starts, vo_batch_strides bs)
 {
-    __shared__ int wcount[FS_THREADS / 64];
-    __shared__ uint32_t raw[FS_DRAWS];
-    __shared__ unsigned short hop[2][FS_DRAWS + 1];
+    __shared__ int wcount[2][FS_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const size_t b = blockIdx.x;
@@ -78,20 +79,19 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         meta = (vo_frame_meta *)((char *)meta + b * bs.out);
         counts = (int *)((char *)counts + b * bs.out);
     }
-    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) raw[p] = (uint32_t)states[p + 1];
-    if (tid <= c0) counts[tid] = 0;
+    for (int c = tid; c <= c0; c += FS_THREADS) counts[c] = 0;
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += FS_THREADS) {
+    for (int i0 = 0, round = 0; i0 < n; i0 += FS_THREADS, ++round) {
         const int i = i0 + tid;
         const bool keep = i < n && status[i] == 1;
         if (i < n) full[i] = 0;
         const unsigned long long b = __ballot(keep);
-        if (lane == 0) wcount[wv] = __popcll(b);
-        __syncthreads();
+        if (lane == 0) wcount[round & 1][wv] = __popcll(b);
+        __syncthreads();          // one barrier per round: the rounds alternate between two sets of counters
         int before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < FS_THREADS / 64; ++w) {
-            const int c = wcount[w];
+            const int c = wcount[round & 1][w];
             before += w < wv ? c : 0;
             total += c;
         }
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
             orig[j] = i;
         }
         base += total;
-        __syncthreads();
     }
+    if (wv != 0) return;
     const int m = base;
-    if (tid == 0) {
+    if (lane == 0) {
         meta->m = m;
         meta->win = -1;
         meta->best = 0;
@@ -115,34 +115,52 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         meta->state = states[0];
     }
     if (m < 4) {
-        if (tid < c0) { subsets[4 * tid] = 0; subsets[4 * tid + 1] = 0; subsets[4 * tid + 2] = 0; subsets[4 * tid + 3] = 0; }
-        if (starts && tid <= c0) starts[tid] = 0;
+        for (int c = lane; c < c0; c += 64) { subsets[4 * c] = 0; subsets[4 * c + 1] = 0; subsets[4 * c + 2] = 0; subsets[4 * c + 3] = 0; }
+        if (starts) for (int c = lane; c <= c0; c += 64) starts[c] = 0;
         return;
     }
-    int idx[4];
-    for (int p = tid; p < FS_DRAWS; p += FS_THREADS) hop[0][p] = (unsigned short)frame_draw_subset(raw, p, (uint32_t)m, idx);
-    if (tid == 0) { hop[0][FS_DRAWS] = FS_DRAWS; hop[1][FS_DRAWS] = FS_DRAWS; }
-    __syncthreads();
-    int pos = 0, cur = 0;
-    for (int k = 0; (1 << k) < c0; ++k) {
-        if (tid < c0 && ((tid >> k) & 1)) pos = hop[cur][pos];
-        for (int p = tid; p < FS_DRAWS; p += FS_THREADS) hop[cur ^ 1][p] = hop[cur][hop[cur][p]];
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (tid < c0) {
-        idx[0] = idx[1] = idx[2] = idx[3] = 0;
-        const int end = pos < FS_DRAWS ? frame_draw_subset(raw, pos, (uint32_t)m, idx) : FS_DRAWS;
-        if (end >= FS_DRAWS) {
-            meta->overflow = 1;
-            idx[0] = idx[1] = idx[2] = idx[3] = 0;
+    int done = 0, pos = 0;          // subsets drawn, draws used (both uniform over the wavefront)
+    bool overflow = false;
+    while (done < c0) {
+        const int p = pos + 4 * lane;
+        int idx[4] = {0, 0, 0, 0};
+        bool ok = false;
+        if (done + lane < c0 && p + 4 < FS_DRAWS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) idx[k] = (int)((uint32_t)states[p + k + 1] % (uint32_t)m);
+            ok = idx[0] != idx[1] && idx[0] != idx[2] && idx[0] != idx[3] && idx[1] != idx[2] && idx[1] != idx[3] && idx[2] != idx[3];
         }
-        subsets[4 * tid] = idx[0]; subsets[4 * tid + 1] = idx[1]; subsets[4 * tid + 2] = idx[2]; subsets[4 * tid + 3] = idx[3];
-        if (starts) {
-            starts[tid] = (unsigned short)pos;
-            if (tid == c0 - 1) starts[c0] = (unsigned short)end;
+        const unsigned long long bad = __ballot(!ok);
+        const int good = bad ? __ffsll((long long)bad) - 1 : 64;       // lanes below: their subsets stand
+        if (lane < good) {
+            const int c = done + lane;
+            subsets[4 * c] = idx[0]; subsets[4 * c + 1] = idx[1]; subsets[4 * c + 2] = idx[2]; subsets[4 * c + 3] = idx[3];
+            if (starts) starts[c] = (unsigned short)p;
+        }
+        done += good;
+        pos += 4 * good;
+        if (done >= c0) break;
+        if (good < 64) {
+            // subset `done` met a repeated index (or the end of the draws): the long way, every lane alike
+            const int end = frame_draw_subset(states, pos, (uint32_t)m, idx);
+            if (end >= FS_DRAWS) { overflow = true; break; }
+            if (lane == 0) {
+                subsets[4 * done] = idx[0]; subsets[4 * done + 1] = idx[1]; subsets[4 * done + 2] = idx[2]; subsets[4 * done + 3] = idx[3];
+                if (starts) starts[done] = (unsigned short)pos;
+            }
+            ++done;
+            pos = end;
         }
     }
+    if (overflow) {
+        if (lane == 0) meta->overflow = 1;
+        for (int c = done + lane; c < c0; c += 64) {
+            subsets[4 * c] = 0; subsets[4 * c + 1] = 0; subsets[4 * c + 2] = 0; subsets[4 * c + 3] = 0;
+            if (starts) starts[c] = FS_DRAWS;
+        }
+        pos = FS_DRAWS;
+    }
+    if (starts && lane == 0) starts[c0] = (unsigned short)pos;
 }
 
 // RANSACUpdateNumIters
@@ -638,7 +656,12 @@ extern "C" int vo_track_pnp_batch_begin(vo_ctx *ctx, const vo_pyr *prev, const v
     unsigned short *d_starts = (unsigned short *)(work + o_starts);
     vo_frame_meta *d_meta = (vo_frame_meta *)(out + o_meta);
     double *d_Rt = (double *)(work + o_Rt), *d_ref = (double *)(out + o_ref);
+    if (ctx->prof_tracker) VO_HIP_CHECK(hipEventRecord(ctx->prof0, ctx->stream));
     if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
+    if (ctx->prof_tracker) {
+        VO_HIP_CHECK(hipEventRecord(ctx->prof1, ctx->stream));
+        ctx->prof_recorded = true;
+    }
     hipLaunchKernelGGL(frame_prep_kernel, dim3(B), dim3(FS_THREADS), 0, ctx->stream, (const uint8_t *)d_status, d_X, (const float *)d_next, n,
                        d_states, states_stride, c0, d_Xc, d_xc, d_orig, d_meta, d_counts, d_full, d_sub, d_starts, bs);
     VO_HIP_CHECK(hipGetLastError());

@@ -61,6 +61,9 @@ struct vo_ctx {
     size_t ba_pool_bytes = 0;
     // device and page-locked state of vo_track_pnp_batch (vo_frame.hip), kept from call to call
     struct vo_frame_batch *fb = nullptr;
+    // vo_profile_tracker: event pair around the tracker launch of the next vo_track_pnp_batch_begin
+    bool prof_tracker = false, prof_recorded = false;
+    hipEvent_t prof0 = nullptr, prof1 = nullptr;
 };
 
 // vo_frame.hip: frees what ctx->fb holds (vo_ctx_destroy)

@@ -56,6 +56,15 @@ class Context:
         check(self.lib.vo_timer_stop_ms(self.handle, ctypes.byref(ms)), "vo_timer_stop_ms")
         return float(ms.value)
 
+    def profile_tracker(self, enable: bool) -> None:
+        """While enabled, TrackPnpBatch.begin brackets its tracker launch with a HIP event pair."""
+        check(self.lib.vo_profile_tracker(self.handle, int(bool(enable))), "vo_profile_tracker")
+
+    def profile_tracker_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(self.lib.vo_profile_tracker_ms(self.handle, ctypes.byref(ms)), "vo_profile_tracker_ms")
+        return float(ms.value)
+
     def close(self) -> None:
         if self.handle:
             self.lib.vo_ctx_destroy(self.handle)

@@ -40,3 +40,13 @@ def max_over_ranks(value: float, device, world: int) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_scalars(value: float, device, world: int) -> List[float]:
+    """Every rank's value, in rank order, on every rank (an imbalanced node shows in the list)."""
+    if world == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
