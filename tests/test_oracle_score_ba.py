@@ -110,3 +110,30 @@ def test_score_pnp_planted(oracle):
     v = (Xc[:, 1] * (1 / Xc[:, 2]) * sc["K"][1, 1] + sc["K"][1, 2]).astype(np.float32)
     e = (sc["m2"][:, 0] - u) ** 2 + (sc["m2"][:, 1] - v) ** 2
     np.testing.assert_array_equal(masks[3], (e <= np.float32(1.0)).astype(np.uint8))
+
+
+@pytest.mark.parametrize("name", ["ba_window_a", "ba_window_b"])
+def test_prefilter_and_costs_match_reference_window(oracle, name):
+    """The reference's _preprocess_data / bundle_adjustment outputs on a window with planted outliers
+    (vo_pipeline/bundleAdjustment.py:69-134): the checker's residual at the start, thresholded the reference's way,
+    keeps exactly the reference's observations, and reproduces the reference's start and final costs."""
+    from scipy.spatial.transform import Rotation
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    F, P = int(d["F"]), int(d["P"])
+
+    def x_of(M, L):
+        cp = np.zeros((F, 6))
+        cp[:, :3] = Rotation.from_matrix(np.asarray(M[:, :, :3], np.float64)).as_rotvec()
+        cp[:, 3:] = M[:, :, 3]
+        return np.hstack([cp.ravel(), np.asarray(L, np.float64).ravel()])
+
+    r, _ = oracle.ba_residual(x_of(d["M"], d["landmarks"]), F, P, d["ci"], d["pi"], d["keypoints"], d["K"])
+    keep = ~((r[0::2] ** 2 + r[1::2] ** 2) > float(d["threshold"]))
+    np.testing.assert_array_equal(d["ci"][keep], d["kept_ci"])
+    np.testing.assert_array_equal(d["pi"][keep], d["kept_pi"])
+    np.testing.assert_array_equal(d["keypoints"][keep], d["kept_keypoints"])
+    assert not keep[d["planted"]].any()
+    for M, L, key in ((d["M"], d["landmarks"], "cost_start"), (d["adjusted_M"], d["adjusted_landmarks"], "cost_final")):
+        r, _ = oracle.ba_residual(x_of(M, L), F, P, d["kept_ci"], d["kept_pi"], d["kept_keypoints"], d["K"])
+        assert 0.5 * float(r @ r) == pytest.approx(float(d[key]), rel=1e-9)
+    assert float(d["cost_final"]) < 0.3 * float(d["cost_start"])

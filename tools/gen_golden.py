@@ -10,6 +10,9 @@ data); no reference source is copied.
 Functions exercised (reference file:line):
   BundleAdjustment._rotate / _reproject / _fun      vo_pipeline/bundleAdjustment.py:14-45
   BundleAdjustment._bundle_adjustment_sparsity      vo_pipeline/bundleAdjustment.py:47-67
+  BundleAdjustment._preprocess_data / bundle_adjustment   vo_pipeline/bundleAdjustment.py:69-134  (these two call
+      cv.Rodrigues; for them, and only for them, the stand-in module gets a Rodrigues built on
+      scipy.spatial.transform.Rotation -- the conversion, not OpenCV's code, so the fixtures record it in `rodrigues`)
   scipy 2-point FD Jacobian through that sparsity   (what least_squares does at :96-97)
   BootstrapInitializer._linear_triangulation        vo_pipeline/bootstrap.py:141-156
   BootstrapInitializer._transform_matrix            vo_pipeline/bootstrap.py:76-138
@@ -89,6 +92,51 @@ def main():
                             J_data=J.data, J_indices=J.indices, J_indptr=J.indptr,
                             n_fixed=int(F / 4) + 1)
         print(name, "O =", ci.size, "cost =", 0.5 * float(r @ r), "nnz(A) =", Acsr.nnz)
+
+    # ---- outlier pre-filter and the whole solve, on two seeded windows with planted outliers -----
+    # Inputs as ContinuousVO._bundle_adjustment hands them over (continuousVO.py:309-313): float32 poses, landmarks and
+    # keypoints, int64 indices sorted by camera.  Stored: what _preprocess_data keeps, what bundle_adjustment returns,
+    # and the cost 0.5*|f|^2 of the reference's own residual at its start and at its solution (kept observations).
+    from scipy.spatial.transform import Rotation
+
+    def rodrigues_shim(x):
+        x = np.asarray(x, np.float64)
+        if x.size == 3:
+            return Rotation.from_rotvec(x.ravel()).as_matrix(), None
+        return Rotation.from_matrix(x).as_rotvec().reshape(3, 1), None
+
+    sys.modules["cv2"].Rodrigues = rodrigues_shim
+    for name, (F, P, vis, seed, n_out) in {"ba_window_a": (6, 200, 0.8, 11, 25), "ba_window_b": (10, 400, 0.6, 12, 60)}.items():
+        x, ci, pi, obs = ba_problem(F, P, vis, seed, K.astype(np.float64))
+        rng = np.random.default_rng(seed + 100)
+        bad = rng.choice(ci.size, n_out, replace=False)
+        obs = obs.copy()
+        obs[bad] += (rng.uniform(12, 80, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))).astype(np.float32)
+        cams = x[:6 * F].reshape(F, 6)
+        M = np.zeros((F, 3, 4), np.float32)
+        for f in range(F):
+            M[f, :, :3] = rodrigues(cams[f, :3])
+            M[f, :, 3] = cams[f, 3:]
+        landmarks = x[6 * F:].reshape(P, 3).astype(np.float32)
+        kp_kept, ci_kept, pi_kept = ba._preprocess_data(M, landmarks, ci, pi, obs)
+        adj_M, adj_L = ba.bundle_adjustment(M, landmarks, ci, pi, obs)
+
+        def cost_at(Mx, Lx):
+            cp = np.zeros((F, 6))
+            for f in range(F):
+                cp[f, :3] = rodrigues_shim(Mx[f, :, :3])[0].ravel()
+                cp[f, 3:] = Mx[f, :, 3]
+            r = ba._fun(np.hstack([cp.ravel(), np.asarray(Lx, np.float64).ravel()]), F, P, ci_kept, pi_kept, kp_kept)
+            return 0.5 * float(r @ r)
+
+        c0, c1 = cost_at(M, landmarks), cost_at(adj_M, adj_L)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), F=F, P=P, K=K, M=M, landmarks=landmarks, ci=ci, pi=pi, keypoints=obs,
+                            planted=np.sort(bad), kept_keypoints=kp_kept, kept_ci=ci_kept, kept_pi=pi_kept, adjusted_M=adj_M,
+                            adjusted_landmarks=adj_L, cost_start=c0, cost_final=c1, n_fixed=int(F / 4) + 1, threshold=100.0,
+                            rodrigues="scipy.spatial.transform.Rotation stand-in for cv.Rodrigues")
+        print(name, "O =", ci.size, "kept =", ci_kept.size, "cost", c0, "->", c1,
+              "frozen cameras moved by", float(np.abs(adj_M[:int(F / 4) + 1] - M[:int(F / 4) + 1]).max()))
+    del sys.modules["cv2"].Rodrigues
 
     # ---- _rotate edge cases (theta == 0 -> points unchanged) ------------------
     rng = np.random.default_rng(3)
