@@ -269,6 +269,21 @@ int vo_ba_create_filtered(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, c
                           int obs_f32, const double *K, const double *x0, double max_sq_error, int n_frozen_cams, int mem,
                           vo_ba **out, int32_t *n_kept, int32_t *obs_start);
 void vo_ba_destroy(vo_ba *ba);
+/* vo_ba_solve: the whole least_squares(...) call of BundleAdjustment.bundle_adjustment
+ * (vo_pipeline/bundleAdjustment.py:96-97) on a solver object, with the loop's decisions on the device: linearise at x0,
+ * then Levenberg-Marquardt trial steps (as vo_ba_try_step) queued several at a time -- after each, one device thread
+ * compares the two costs, accepts (damping / 3) or rejects (damping x 10) and applies the stop rules: an accepted step that
+ * gained less than ftol of the cost (stop_reason 1), a rejected step that moved the cost by less than ftol (2; only with
+ * stop_on_flat_reject), ten rejected steps in a row (3), max_iters accepted steps (4).  The host reads the bookkeeping
+ * record back once per round of queued steps instead of one cost per step.  x0 and x_out (6F+3P float64) follow `mem`;
+ * stats (host, may be NULL).  The decisions are those of a host loop over vo_ba_linearize / vo_ba_try_step / vo_ba_accept
+ * with the same rules.  Synchronises the stream. */
+typedef struct vo_ba_lm_stats {
+    double cost_start, cost_final, lambda;
+    int32_t trial_steps, accepted, iterations, stop_reason;
+} vo_ba_lm_stats;
+int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
+                int stop_on_flat_reject, double *x_out, int mem, vo_ba_lm_stats *stats);
 int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost);
 int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved);
 int vo_ba_accept(vo_ctx *ctx, vo_ba *ba);

@@ -248,3 +248,94 @@ def test_filtered_solver_edge_cases(ctx):
         hip.BaSolver.filtered(ctx, 5, 60, ci, bad, obs, K, x0, 100.0, 2)
     with pytest.raises(ValueError):
         hip.BaSolver.filtered(ctx, 5, 60, ci, pi[:-1], obs, K, x0, 100.0, 2)
+
+
+@pytest.mark.parametrize("F,P,vis,flat", [(6, 150, 0.7, True), (12, 300, 0.5, True), (30, 600, 0.3, True), (8, 200, 0.6, False),
+                                          (45, 500, 0.25, True)])
+def test_device_side_loop_equals_host_loop(ctx, F, P, vis, flat):
+    """vo_ba_solve (accept / reject, damping and the stop rules decided by a device thread, trial steps queued without
+    the host in between) against the same loop driven from the host over vo_ba_linearize / try_step / accept: same
+    number of trial and accepted steps, same final cost and parameters (float64 sums through atomics differ in the last
+    bits from run to run, so equality is to 1e-9, and a run whose decision hangs on such bits is not among the cases)."""
+    from visual_odometry_amd import hip
+    from visual_odometry_amd.vo_pipeline.bundleAdjustment import BundleAdjustment
+    pb = synth.ba_problem(F=F, P=P, visibility=vis, seed=300 + F, obs_noise=0.4)
+    ci, pi, K, obs = pb["ci"], pb["pi"], pb["K"], pb["obs"].astype(np.float64)
+    front = pb["x"][6 * F:].reshape(P, 3)[pi, 2] - 0.5 * ci > 3.0        # the cameras advance 0.5 per frame: keep what lies ahead
+    ci, pi, obs = ci[front], pi[front], obs[front]
+    rng = np.random.default_rng(F)
+    x0 = pb["x"].copy()
+    x0[6 * (int(F / 4) + 1):6 * F] += rng.normal(0, 5e-3, 6 * F - 6 * (int(F / 4) + 1))
+    x0[6 * F:] += rng.normal(0, 0.05, 3 * P)
+    start = int(np.count_nonzero(ci < int(F / 4) + 1))
+
+    class Counting:
+        def __init__(self, s):
+            self.s, self.O, self.trials, self.accepted = s, s.O, 0, 0
+
+        def linearize(self, x):
+            self.c0 = self.s.linearize(x)
+            return self.c0
+
+        def try_step(self, lam):
+            self.trials += 1
+            self.last = self.s.try_step(lam)
+            return self.last
+
+        def accept(self):
+            self.accepted += 1
+            self.cost = self.last[0]
+            self.s.accept()
+
+        def params(self):
+            return self.s.params()
+
+        def close(self):
+            self.s.close()
+
+    host = Counting(hip.BaSolver(ctx, F, P, ci, pi, obs, K, start))
+    x_host = BundleAdjustment(K)._levenberg_marquardt(x0, host, 50, 1e-4, stop_on_flat_reject=flat)
+    dev = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+    try:
+        x_dev, st = dev.solve(x0, 50, 1e-4, 1e-3, flat)
+    finally:
+        dev.close()
+    assert (st["trial_steps"], st["accepted"]) == (host.trials, host.accepted), (st, host.trials, host.accepted)
+    assert st["cost_start"] == pytest.approx(host.c0, rel=1e-12)
+    assert st["cost_final"] == pytest.approx(host.cost, rel=1e-9)
+    assert st["cost_final"] < 0.9 * st["cost_start"] and st["stop_reason"] in (1, 2, 3)
+    # (a landmark seen by two or three neighbouring cameras is determined along its ray to ~1e-7 of its depth only)
+    np.testing.assert_allclose(x_dev, x_host, rtol=2e-6, atol=1e-6)
+    # the drop-in class: both routes end at the same place
+    from scipy.spatial.transform import Rotation
+    M = np.zeros((F, 3, 4))
+    cams = x0[:6 * F].reshape(F, 6)
+    M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
+    M[:, :, 3] = cams[:, 3:]
+    L0 = x0[6 * F:].reshape(P, 3)
+    a = BundleAdjustment(K).bundle_adjustment(M, L0, ci, pi, obs, stop_on_flat_reject=flat, device_loop=True)
+    b = BundleAdjustment(K).bundle_adjustment(M, L0, ci, pi, obs, stop_on_flat_reject=flat, device_loop=False)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-7)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-6, atol=1e-6)
+
+
+def test_device_side_loop_empty_and_frozen_windows(ctx):
+    from visual_odometry_amd import hip
+    pb = synth.ba_problem(F=5, P=60, visibility=0.8, seed=4, obs_noise=0.3)
+    ci, pi, K, obs, x0 = pb["ci"], pb["pi"], pb["K"], pb["obs"].astype(np.float64), pb["x"]
+    s = hip.BaSolver(ctx, 5, 60, ci[:0], pi[:0], obs[:0], K, 0)               # no observations: the start comes back
+    x, st = s.solve(x0)
+    s.close()
+    np.testing.assert_array_equal(x, x0)
+    assert st["trial_steps"] == 0
+    s = hip.BaSolver(ctx, 5, 60, ci, pi, obs, K, ci.size)                     # every observation frozen: ten rejected steps
+    x, st = s.solve(x0)
+    s.close()
+    np.testing.assert_array_equal(x, x0)
+    assert st["accepted"] == 0 and st["stop_reason"] in (2, 3)
+    s = hip.BaSolver(ctx, 5, 60, ci, pi, obs, K, int(np.count_nonzero(ci < 2)))
+    with pytest.raises(ValueError):
+        s.solve(x0[:-1])
+    x, st = s.solve(x0, max_iters=2)                                          # the iteration cap
+    assert st["accepted"] <= 2
+    s.close()

@@ -229,6 +229,10 @@ def test_levenberg_marquardt_loop_endings():
     s = _ScriptedSolver([100.0, 50.0, 50.004, 49.0])
     ba._levenberg_marquardt("x0", s, 50, 1e-4)
     assert s.accepted == 1 and len(s.tried) == 2 and s.closed
+    # with the rule switched off the same script goes on: the tenfold damped step gains more than ftol and is taken
+    s = _ScriptedSolver([100.0, 50.0, 50.004, 49.0, 48.9999])
+    ba._levenberg_marquardt("x0", s, 50, 1e-4, stop_on_flat_reject=False)
+    assert s.accepted == 3 and len(s.tried) == 4 and s.tried[2] == pytest.approx(10 * s.tried[1]) and s.closed
     # ... a larger increase does not: ten rejected steps in a row do
     s = _ScriptedSolver([100.0] + [101.0] * 10 + [1.0])
     ba._levenberg_marquardt("x0", s, 50, 1e-4)

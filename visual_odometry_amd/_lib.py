@@ -17,6 +17,12 @@ VO_MEM_HOST = 0
 VO_MEM_DEVICE = 1
 
 
+class BaLmStats(ctypes.Structure):
+    _fields_ = [("cost_start", ctypes.c_double), ("cost_final", ctypes.c_double), ("lam", ctypes.c_double),
+                ("trial_steps", ctypes.c_int32), ("accepted", ctypes.c_int32), ("iterations", ctypes.c_int32),
+                ("stop_reason", ctypes.c_int32)]
+
+
 class KltParams(ctypes.Structure):
     _fields_ = [("max_iters", ctypes.c_int), ("eps", ctypes.c_float), ("min_eig", ctypes.c_float)]
 
@@ -74,6 +80,8 @@ SIGNATURES = {
                                              ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp),
                                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "vo_ba_destroy": (None, [c_vp]),
+    "vo_ba_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_vp, ctypes.c_int,
+                                   c_vp]),
     "vo_ba_linearize": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p]),
     "vo_ba_try_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_f64p, ctypes.POINTER(ctypes.c_int)]),
     "vo_ba_accept": (ctypes.c_int, [c_vp, c_vp]),

@@ -48,6 +48,14 @@ __device__ __forceinline__ double wave_sum_d(double v)
 
 struct BaK { double k[9]; };
 
+// Levenberg-Marquardt bookkeeping of vo_ba_solve, kept on the device so that trial steps can be queued without the
+// host reading a cost in between: the damping the next trial step uses, the cost at the current point, counters and
+// the stop flag.  Kernels of a trial step that are handed the record leave at once when `done` is set.
+struct BaCtl {
+    double lambda, cost, prev, ftol, cost_start;
+    int done, copy_now, tries, iters, max_iters, trials, accepted, reason, flat_reject, pad;
+};
+
 template <bool WITH_J>
 __device__ __forceinline__ void ba_obs(const double *cam, const double *X, const BaK &K, const double *ob,
                                        double *r, double *Jc, double *Jp)
@@ -139,8 +147,10 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
                                                         double *__restrict__ cam_rep, double *__restrict__ cost_slots,
                                                         double *__restrict__ Jp_out = nullptr,
                                                         const int *__restrict__ list_start = nullptr,
-                                                        const int *__restrict__ list_slot = nullptr, int *__restrict__ list_obs = nullptr)
+                                                        const int *__restrict__ list_slot = nullptr, int *__restrict__ list_obs = nullptr,
+                                                        const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl && ctl->done) return;
     const int i = blockIdx.x * BA_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < O;
@@ -293,8 +303,10 @@ __global__ __launch_bounds__(BA_THREADS) void ba_kernel(const double *__restrict
 // Hpp given, the lower triangles of the landmark blocks are filled from the upper ones.
 __global__ __launch_bounds__(256) void ba_cam_sum_kernel(int F, const double *__restrict__ cam_rep, double *__restrict__ Hcc,
                                                          double *__restrict__ g, int P, double *__restrict__ Hpp,
-                                                         const double *__restrict__ cost_slots, double *__restrict__ cost)
+                                                         const double *__restrict__ cost_slots, double *__restrict__ cost,
+                                                         const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl && ctl->done) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (cost_slots && t < 64) {                   // cost = sum of the slots (overwrites)
         double s = 0;
@@ -981,6 +993,8 @@ struct vo_ba {
            *Hpp[2] = {nullptr, nullptr}, *Hcp[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};
     int cur = 0;
     bool linearized = false, have_candidate = false;
+    BaCtl *ctl = nullptr;      // vo_ba_solve's bookkeeping record
+    size_t slot_bytes = 0;     // one slot's {x, cost, Hcc, Hpp, Hcp, g} are one contiguous block of this size
     size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
     size_t solve6_lds = 0; // LDS of the camera-at-a-time solve of such a system (0: the column-at-a-time kernel)
     int solve_w = 0;       // panel width of the blocked solve of a system that is not (0: the column-at-a-time kernel)
@@ -1030,9 +1044,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_kernel(int n, int P, i
                                                                  const double *__restrict__ Hpp, const double *__restrict__ Hcp,
                                                                  const double *__restrict__ g, double lambda,
                                                                  double *__restrict__ Dpinv, double *__restrict__ S,
-                                                                 double *__restrict__ rhs)
+                                                                 double *__restrict__ rhs, const BaCtl *__restrict__ ctl = nullptr)
 {
     extern __shared__ double sl[];
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     double *Sa = LDS ? sl : S, *ra = LDS ? sl + (size_t)n * n : rhs;
     if (LDS) {
         for (int i = threadIdx.x; i < n * n + n; i += SCHUR_THREADS) sl[i] = 0.0;
@@ -1123,9 +1138,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, in
                                                                        const double *__restrict__ Hpp, const double *__restrict__ Hcp,
                                                                        const double *__restrict__ g, double lambda,
                                                                        double *__restrict__ Dpinv, double *__restrict__ S,
-                                                                       double *__restrict__ rhs)
+                                                                       double *__restrict__ rhs, const BaCtl *__restrict__ ctl = nullptr)
 {
     extern __shared__ double sl[];
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     int c0, c1;                                                            // cameras of this strip
     if (!ba_strip_bounds(cam_first, F, budget, blockIdx.y, c0, c1)) return;
     // only columns from the first camera with unknowns up to the strip's own diagonal blocks are needed
@@ -1209,9 +1225,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, in
 template <bool LDS>
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, double *__restrict__ S, double *__restrict__ rhs,
                                                                  const double *__restrict__ Hcc, const double *__restrict__ g,
-                                                                 double lambda, double *__restrict__ dc, int *__restrict__ flag)
+                                                                 double lambda, double *__restrict__ dc, int *__restrict__ flag,
+                                                                 const BaCtl *__restrict__ ctl = nullptr)
 {
     extern __shared__ double sl[];
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     __shared__ int fail;
     __shared__ unsigned char dead_cam[256];
     double *A = LDS ? sl : S, *b = LDS ? sl + (size_t)n * n : rhs, *dinv = LDS ? sl + (size_t)n * n + n : dc;
@@ -1291,8 +1309,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(int n, int F, d
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve6_kernel(int n, int F, const double *__restrict__ S,
                                                                   const double *__restrict__ rhs, const double *__restrict__ Hcc,
                                                                   const double *__restrict__ g, double lambda,
-                                                                  double *__restrict__ dc, int *__restrict__ flag)
+                                                                  double *__restrict__ dc, int *__restrict__ flag,
+                                                                  const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     extern __shared__ double sl[];
     __shared__ unsigned char dead_cam[256];
     const int ld = SOLVE6_LD(n), tid = threadIdx.x;
@@ -1531,9 +1551,10 @@ __device__ __forceinline__ bool solveb_triangle(double (&tv)[SOLVEB_MAX_W], doub
 // clears flag[0], and later launches return at once.
 __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w, double *A, double *b, double *__restrict__ Lf,
                                                             double *__restrict__ zf, double *__restrict__ dinv,
-                                                            int *__restrict__ flag)
+                                                            int *__restrict__ flag, const BaCtl *__restrict__ ctl = nullptr)
 {
     __shared__ double tile[PANEL_MAX_W * 64];
+    if (ctl && ctl->done) return;
     if (flag[0] == 0) return;
     const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     const int t0 = k0 + w, m = n - t0;          // trailing rows 0 .. m (row m: the right-hand side), columns 0 .. m-1
@@ -1638,8 +1659,9 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
 __global__ __launch_bounds__(256) void ba_solve_prep_kernel(int n, int F, int first, double *__restrict__ A, double *__restrict__ b,
                                                             const double *__restrict__ Hcc, const double *__restrict__ g,
                                                             double lambda, double *__restrict__ zf, double *__restrict__ dinv,
-                                                            int *__restrict__ flag)
+                                                            int *__restrict__ flag, const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) flag[0] = 1;
     if (t < F * 36) {
@@ -1665,8 +1687,10 @@ __global__ __launch_bounds__(256) void ba_solve_prep_kernel(int n, int F, int fi
 __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n, int F, int first, int W, double *__restrict__ A,
                                                                           double *__restrict__ b, const double *__restrict__ Hcc,
                                                                           const double *__restrict__ g, double lambda,
-                                                                          int *__restrict__ flag, double *__restrict__ dinv_g)
+                                                                          int *__restrict__ flag, double *__restrict__ dinv_g,
+                                                                          const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
     extern __shared__ double sl[];
     __shared__ unsigned char dead_cam[256];
     const int ld = n + 1;                       // panel column length (rows k0 .. n, the last one the right-hand side)
@@ -1819,8 +1843,9 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
 __global__ __launch_bounds__(SOLVEB_THREADS) void ba_backsolve_kernel(int n, int F, int first, int W, const double *__restrict__ A,
                                                                       const double *__restrict__ b, const double *__restrict__ dinv_g,
                                                                       const double *__restrict__ Hcc, double *__restrict__ dc,
-                                                                      const int *__restrict__ flag)
+                                                                      const int *__restrict__ flag, const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl && ctl->done) return;
     extern __shared__ double sl[];
     __shared__ unsigned char dead_cam[256];
     __shared__ double xs[SOLVEB_MAX_W];
@@ -1903,8 +1928,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, co
                                                          const double *__restrict__ Hpp, const double *__restrict__ Hcp,
                                                          const double *__restrict__ g, const double *__restrict__ Dpinv,
                                                          const double *__restrict__ dc, const double *__restrict__ x,
-                                                         double *__restrict__ x_new)
+                                                         double *__restrict__ x_new, const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl && ctl->done) return;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < n) x_new[p] = x[p] + dc[p];
     if (p >= P) return;
@@ -1934,8 +1960,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, co
 __global__ __launch_bounds__(256) void ba_point_gather_kernel(int P, int F, const int *__restrict__ pptr,
                                                               const int *__restrict__ pobs, const double *__restrict__ Jp,
                                                               const double *__restrict__ r, double *__restrict__ Hpp,
-                                                              double *__restrict__ g)
+                                                              double *__restrict__ g, const BaCtl *__restrict__ ctl = nullptr)
 {
+    if (ctl && ctl->done) return;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
@@ -1956,7 +1983,7 @@ __global__ __launch_bounds__(256) void ba_point_gather_kernel(int P, int F, cons
     gq[0] = gp[0]; gq[1] = gp[1]; gq[2] = gp[2];
 }
 
-static int ba_linearize_into(vo_ba *ba, int slot)
+static int ba_linearize_into(vo_ba *ba, int slot, const BaCtl *ctl = nullptr)
 {
     vo_ctx *ctx = ba->ctx;
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
@@ -1968,14 +1995,15 @@ static int ba_linearize_into(vo_ba *ba, int slot)
         const unsigned blocks = (unsigned)((ba->O + BA_THREADS - 1) / BA_THREADS);
         hipLaunchKernelGGL((ba_kernel<true, true>), dim3(blocks), dim3(BA_THREADS), 0, ctx->stream, ba->x[slot], ba->F, ba->P,
                            ba->ci, ba->pi, ba->obs, ba->O, ba->K, ba->obs_start, ba->r, ba->cost[slot], ba->Hcc[slot],
-                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->cam_rep, ba->cam_rep + cam_doubles, ba->Jp);
+                           ba->Hpp[slot], ba->Hcp[slot], ba->g[slot], ba->cam_rep, ba->cam_rep + cam_doubles, ba->Jp,
+                           (const int *)nullptr, (const int *)nullptr, (int *)nullptr, ctl);
         VO_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((ba->F * 42 + 255) / 256), dim3(256), 0, ctx->stream, ba->F, ba->cam_rep,
-                       ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr, (const double *)(ba->cam_rep + cam_doubles), ba->cost[slot]);
+                       ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr, (const double *)(ba->cam_rep + cam_doubles), ba->cost[slot], ctl);
     VO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
-                       ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot]);
+                       ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot], ctl);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
@@ -1994,7 +2022,7 @@ static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **o
     const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
                  o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
                  o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
-                 o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8);
+                 o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8), o_ctl = take(sizeof(BaCtl));
     size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
     for (int s = 0; s < 2; ++s) {
         o_x[s] = take(np_ * 8); o_cost[s] = take(8); o_Hcc[s] = take((size_t)F * 288); o_Hpp[s] = take((size_t)P * 72);
@@ -2034,6 +2062,8 @@ static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **o
     ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
     ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
     ba->Lf = (double *)(b + o_Lf); ba->zf = (double *)(b + o_zf); ba->dinv = (double *)(b + o_dinv);
+    ba->ctl = (BaCtl *)(b + o_ctl);
+    ba->slot_bytes = o_x[1] - o_x[0];
     for (int s = 0; s < 2; ++s) {
         ba->x[s] = (double *)(b + o_x[s]); ba->cost[s] = (double *)(b + o_cost[s]); ba->Hcc[s] = (double *)(b + o_Hcc[s]);
         ba->Hpp[s] = (double *)(b + o_Hpp[s]); ba->Hcp[s] = (double *)(b + o_Hcp[s]); ba->g[s] = (double *)(b + o_g[s]);
@@ -2434,13 +2464,12 @@ extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem,
     return VO_OK;
 }
 
-extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved)
+// One trial step queued on the context's stream: candidate = current + LM step for the damping `lambda` (or, with
+// ctl, the damping the device-side record holds; every kernel then leaves at once when the record says done),
+// linearised into the other slot.
+static int ba_try_step_enqueue(vo_ba *ba, double lambda, const BaCtl *ctl)
 {
-    VO_REQUIRE(ctx && ba && cost_new && solved, "vo_ba_try_step: NULL argument");
-    VO_REQUIRE(ba->ctx == ctx, "vo_ba_try_step: solver belongs to another context");
-    VO_REQUIRE(lambda >= 0, "vo_ba_try_step: lambda=%g", lambda);
-    if (!ba->linearized) { vo_set_error("vo_ba_try_step: call vo_ba_linearize first"); return VO_ESTATE; }
-    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    vo_ctx *ctx = ba->ctx;
     const int c = ba->cur, o = 1 - c, n = ba->n;
     VO_HIP_CHECK(hipMemsetAsync(ba->S, 0, ((size_t)n * n + 0) * 8, ctx->stream));
     VO_HIP_CHECK(hipMemsetAsync(ba->rhs, 0, (size_t)n * 8, ctx->stream));
@@ -2449,7 +2478,7 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
     if (blocks > 128) blocks = 128;
     if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(blocks), dim3(SCHUR_THREADS), ba->lds_bytes, ctx->stream, n, ba->P, ba->F,
-                           ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
+                           ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs, ctl);
     else if (ba->n_strips) {
         const int strips = ba->n_strips;
         int slices = (ba->P + waves - 1) / waves;
@@ -2459,51 +2488,172 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
         if (slices > want) slices = want;
         hipLaunchKernelGGL(ba_schur_strip_kernel, dim3(slices, strips), dim3(SCHUR_THREADS), ba->strip_lds, ctx->stream, n, ba->P,
                            ba->F, ba->cam_first, ba->strip_budget, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
-                           ba->S, ba->rhs);
+                           ba->S, ba->rhs, ctl);
     } else
         hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(blocks), dim3(SCHUR_THREADS), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
-                           ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs);
+                           ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv, ba->S, ba->rhs, ctl);
     VO_HIP_CHECK(hipGetLastError());
     if (ba->lds_bytes && ba->solve6_lds)
         hipLaunchKernelGGL(ba_solve6_kernel, dim3(1), dim3(SOLVE_THREADS), ba->solve6_lds, ctx->stream, n, ba->F, (const double *)ba->S,
-                           (const double *)ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+                           (const double *)ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag, ctl);
     else if (ba->lds_bytes)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), ba->lds_bytes, ctx->stream, n, ba->F, ba->S,
-                           ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+                           ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag, ctl);
     else if (ba->panels) {
         const int first = 6 * ba->cam_first, W = PANEL_MAX_W;
         const int work = ba->F * 36 > n ? ba->F * 36 : n;
         hipLaunchKernelGGL(ba_solve_prep_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, n, ba->F, first, ba->S, ba->rhs,
-                           ba->Hcc[c], ba->g[c], lambda, ba->zf, ba->dinv, ba->flag);
+                           ba->Hcc[c], ba->g[c], lambda, ba->zf, ba->dinv, ba->flag, ctl);
         for (int k0 = first; k0 < n; k0 += W) {
             const int w = n - k0 < W ? n - k0 : W, m = n - k0 - w, nb = (m + 1 + 31) / 32;
             hipLaunchKernelGGL(ba_solve_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S, ba->rhs,
-                               ba->Lf, ba->zf, ba->dinv, ba->flag);
+                               ba->Lf, ba->zf, ba->dinv, ba->flag, ctl);
         }
         hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, first,
                            ba->solve_w, (const double *)ba->Lf, (const double *)ba->zf, (const double *)ba->dinv, ba->Hcc[c], ba->dc,
-                           (const int *)ba->flag);
+                           (const int *)ba->flag, ctl);
     } else if (ba->solve_w) {
         hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
-                           6 * ba->cam_first, ba->solve_w, ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->flag, ba->dinv);
+                           6 * ba->cam_first, ba->solve_w, ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->flag, ba->dinv, ctl);
         hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
                            6 * ba->cam_first, ba->solve_w, (const double *)ba->S, (const double *)ba->rhs, (const double *)ba->dinv,
-                           ba->Hcc[c], ba->dc, (const int *)ba->flag);
+                           ba->Hcc[c], ba->dc, (const int *)ba->flag, ctl);
     }
     else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
-                           ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag);
+                           ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag, ctl);
     VO_HIP_CHECK(hipGetLastError());
     const int work = ba->P > n ? ba->P : n;
     hipLaunchKernelGGL(ba_backsub_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
-                       ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], ba->Dpinv, ba->dc, ba->x[c], ba->x[o]);
+                       ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], ba->Dpinv, ba->dc, ba->x[c], ba->x[o], ctl);
     VO_HIP_CHECK(hipGetLastError());
-    int rc = ba_linearize_into(ba, o);
+    return ba_linearize_into(ba, o, ctl);
+}
+
+extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved)
+{
+    VO_REQUIRE(ctx && ba && cost_new && solved, "vo_ba_try_step: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_try_step: solver belongs to another context");
+    VO_REQUIRE(lambda >= 0, "vo_ba_try_step: lambda=%g", lambda);
+    if (!ba->linearized) { vo_set_error("vo_ba_try_step: call vo_ba_linearize first"); return VO_ESTATE; }
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ba_try_step_enqueue(ba, lambda, nullptr);
     if (rc) return rc;
-    VO_RESULT(ctx, cost_new, ba->cost[o], 8);
+    VO_RESULT(ctx, cost_new, ba->cost[1 - ba->cur], 8);
     VO_RESULT(ctx, solved, ba->flag, 4);
     VO_RESULTS_FINISH(ctx);
     ba->have_candidate = true;
+    return VO_OK;
+}
+
+// ---- the whole Levenberg-Marquardt loop with the decisions on the device ------------------------------------
+// After a trial step one thread compares the candidate's cost with the current point's and updates the record: an
+// accepted step lowers the damping to a third and asks for the candidate to be copied over the current point (the two
+// slots are contiguous blocks; the copy is a few microseconds at HBM speed and keeps every kernel's pointers fixed), a
+// rejected one raises it tenfold; the stop rules are those of the host loop (gain below ftol after an accepted
+// step, a rejected step that moved the cost by less than ftol, ten rejected steps in a row, the iteration cap).
+__global__ void ba_lm_init_kernel(BaCtl *ctl, const double *__restrict__ cost, double lambda0, double ftol, int max_iters, int flat_reject)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    ctl->lambda = lambda0;
+    ctl->cost = ctl->prev = ctl->cost_start = cost[0];
+    ctl->ftol = ftol;
+    ctl->done = max_iters <= 0;
+    ctl->copy_now = 0;
+    ctl->tries = ctl->iters = ctl->trials = ctl->accepted = ctl->reason = 0;
+    ctl->max_iters = max_iters;
+    ctl->flat_reject = flat_reject;
+    ctl->pad = 0;
+}
+
+__global__ void ba_lm_control_kernel(BaCtl *ctl, const double *__restrict__ cost_new_p, const int *__restrict__ flag)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    ctl->copy_now = 0;
+    if (ctl->done) return;
+    const double cost_new = cost_new_p[0], cost = ctl->cost;
+    const bool usable = flag[0] != 0 && isfinite(cost_new);
+    ctl->trials++;
+    if (usable && cost_new < cost) {
+        ctl->copy_now = 1;
+        ctl->accepted++;
+        ctl->cost = cost_new;
+        ctl->lambda = fmax(ctl->lambda / 3, 1e-9);
+        ctl->tries = 0;
+        ctl->iters++;
+        if ((ctl->prev - cost_new) < ctl->ftol * ctl->prev) { ctl->done = 1; ctl->reason = 1; }
+        else if (ctl->iters >= ctl->max_iters) { ctl->done = 1; ctl->reason = 4; }
+        ctl->prev = cost_new;
+    } else if (ctl->flat_reject && usable && fabs(cost_new - cost) < ctl->ftol * cost) {
+        ctl->done = 1;
+        ctl->reason = 2;
+    } else {
+        ctl->lambda *= 10;
+        if (++ctl->tries >= 10) { ctl->done = 1; ctl->reason = 3; }
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_lm_copy_kernel(const BaCtl *__restrict__ ctl, uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    if (!ctl->copy_now) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
+                           int stop_on_flat_reject, double *x_out, int mem, vo_ba_lm_stats *stats)
+{
+    VO_REQUIRE(ctx && ba && x0 && x_out, "vo_ba_solve: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_solve: solver belongs to another context");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_solve: bad mem flag %d", mem);
+    VO_REQUIRE(max_iters >= 0 && ftol >= 0 && lambda0 > 0, "vo_ba_solve: max_iters=%d ftol=%g lambda0=%g", max_iters, ftol, lambda0);
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
+    const int c = ba->cur, o = 1 - c;
+    if (mem == VO_MEM_HOST) VO_UPLOAD(ctx, ba->x[c], x0, np_ * 8);
+    else VO_HIP_CHECK(hipMemcpyAsync(ba->x[c], x0, np_ * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = ba_linearize_into(ba, c);
+    if (rc) return rc;
+    ba->linearized = true;
+    ba->have_candidate = false;
+    hipLaunchKernelGGL(ba_lm_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ba->ctl, (const double *)ba->cost[c], lambda0, ftol,
+                       ba->O == 0 ? 0 : max_iters, stop_on_flat_reject);
+    VO_HIP_CHECK(hipGetLastError());
+    BaCtl h = {};
+    const size_t n16 = ba->slot_bytes / 16;
+    unsigned copy_blocks = (unsigned)((n16 + 255) / 256);
+    if (copy_blocks > 4096) copy_blocks = 4096;
+    // Trial steps are queued several at a time and the record read back once per round: a window needs 5-8 of them,
+    // and a surplus step behind the one that ended the loop costs its launches only (every kernel leaves on `done`).
+    const int cap = ba->O == 0 ? 0 : 10 * (max_iters > 0 ? max_iters : 1);
+    if (cap == 0) {
+        VO_RESULT(ctx, &h, ba->ctl, sizeof(BaCtl));
+        VO_RESULTS_FINISH(ctx);
+    }
+    for (int queued = 0, round = 0; queued < cap; ++round) {
+        int batch = round == 0 ? 6 : 4;
+        if (batch > cap - queued) batch = cap - queued;
+        for (int k = 0; k < batch; ++k) {
+            if ((rc = ba_try_step_enqueue(ba, 0.0, ba->ctl))) return rc;
+            hipLaunchKernelGGL(ba_lm_control_kernel, dim3(1), dim3(64), 0, ctx->stream, ba->ctl, (const double *)ba->cost[o], (const int *)ba->flag);
+            hipLaunchKernelGGL(ba_lm_copy_kernel, dim3(copy_blocks), dim3(256), 0, ctx->stream, (const BaCtl *)ba->ctl, (uint4 *)ba->x[c],
+                               (const uint4 *)ba->x[o], n16);
+            VO_HIP_CHECK(hipGetLastError());
+        }
+        queued += batch;
+        VO_RESULT(ctx, &h, ba->ctl, sizeof(BaCtl));
+        VO_RESULTS_FINISH(ctx);
+        if (h.done) break;
+    }
+    if (mem == VO_MEM_HOST) {
+        VO_RESULT(ctx, x_out, ba->x[c], np_ * 8);
+        VO_RESULTS_FINISH(ctx);
+    } else {
+        VO_HIP_CHECK(hipMemcpyAsync(x_out, ba->x[c], np_ * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (stats) {
+        stats->cost_start = h.cost_start; stats->cost_final = h.cost; stats->lambda = h.lambda;
+        stats->trial_steps = h.trials; stats->accepted = h.accepted; stats->iterations = h.iters; stats->stop_reason = h.reason;
+    }
     return VO_OK;
 }
 

@@ -808,6 +808,19 @@ class BaSolver:
     def accept(self) -> None:
         check(self.ctx.lib.vo_ba_accept(self.ctx.handle, self.handle), "vo_ba_accept")
 
+    def solve(self, x0, max_iters: int = 50, ftol: float = 1e-4, lam0: float = 1e-3, stop_on_flat_reject: bool = True):
+        """The whole Levenberg-Marquardt loop from x0 with the accept / reject decisions on the device (vo_ba_solve):
+        trial steps are queued several at a time, the host reads the loop's record once per round -> (x (6F+3P) float64,
+        stats: cost_start, cost_final, lam, trial_steps, accepted, iterations, stop_reason)."""
+        x0 = np.ascontiguousarray(x0, np.float64).ravel()
+        if x0.size != 6 * self.F + 3 * self.P:
+            raise ValueError(f"BaSolver.solve: parameter vector has {x0.size} entries, expected {6 * self.F + 3 * self.P}")
+        x = np.empty_like(x0)
+        st = _lib.BaLmStats()
+        check(self.ctx.lib.vo_ba_solve(self.ctx.handle, self.handle, _ptr(x0), int(max_iters), float(ftol), float(lam0),
+                                       int(bool(stop_on_flat_reject)), _ptr(x), VO_MEM_HOST, ctypes.byref(st)), "vo_ba_solve")
+        return x, {k: getattr(st, k) for k, _ in st._fields_}
+
     def params(self, candidate: bool = False) -> np.ndarray:
         x = np.empty(6 * self.F + 3 * self.P, np.float64)
         check(self.ctx.lib.vo_ba_params(self.ctx.handle, self.handle, int(candidate), _ptr(x), VO_MEM_HOST), "vo_ba_params")

@@ -5,11 +5,15 @@ the reference's problem definition -- outlier pre-filter, parameter vector
 [F x (rvec, t) | P x XYZ], first int(F/4)+1 cameras and their observation rows
 frozen, cost 0.5*|r|^2, ftol 1e-4 -- but where the reference hands scipy's TRF a
 finite-difference Jacobian, this runs Levenberg-Marquardt on the analytic normal
-equations with a Schur complement on the landmarks, all on the GPU (vo_ba_create /
-vo_ba_try_step / vo_ba_accept).  Iterates therefore differ from scipy's; the
-residual, cost and Jacobian at a given x are the same.  A window ends when an accepted
-step gains less than ftol of the cost, when a rejected step moved it by less than that
-(stronger damping could only gain less), or after ten rejected steps in a row.
+equations with a Schur complement on the landmarks, all on the GPU, the loop's
+accept / reject decisions included (vo_ba_solve: trial steps are queued several at a
+time and the host reads the loop's record once per round).  Iterates therefore differ
+from scipy's; the residual, cost and Jacobian at a given x are the same.  A window ends
+when an accepted step gains less than ftol of the cost, when a rejected step moved it by
+less than that (`stop_on_flat_reject`, on by default: with the frozen cameras'
+observations in the cost but not in the Jacobian a window typically ends in a run of
+rejected steps whose cost change shrinks tenfold per try; scipy has no such rule),
+or after ten rejected steps in a row.
 """
 from typing import Tuple
 
@@ -110,13 +114,18 @@ class BundleAdjustment:
     # ---- solve ------------------------------------------------------------------
     def bundle_adjustment(self, M: np.ndarray, landmarks: np.ndarray, camera_indices: np.ndarray,
                           point_indices: np.ndarray, keypoints: np.ndarray,
-                          max_iters: int = 50, ftol: float = 1e-4) -> Tuple[np.ndarray, np.ndarray]:
+                          max_iters: int = 50, ftol: float = 1e-4, stop_on_flat_reject: bool = True,
+                          device_loop: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         """
         :param M:               (F, 3, 4) camera poses [R|t]
         :param landmarks:       (P, 3) point cloud
         :param camera_indices:  (O,) frame index of each observation, ascending
         :param point_indices:   (O,) landmark index of each observation
         :param keypoints:       (O, 2) observed pixels
+        :param stop_on_flat_reject: end the window on a rejected step that moved the cost by less than ftol
+                                (False: keep raising the damping, up to ten rejected steps in a row)
+        :param device_loop:     the loop's decisions on the GPU (vo_ba_solve); False: the same loop on the host, one
+                                cost read-back per trial step
         :return (adjusted_M (F,3,4) float64, adjusted_landmarks (P,3) float64)
         """
         camera_indices = np.asarray(camera_indices, np.int64)
@@ -128,7 +137,14 @@ class BundleAdjustment:
             # lists in one library call: the observations cross to the device once
             solver = hip.BaSolver.filtered(_runtime.context(), F, P, camera_indices, point_indices,
                                            keypoints, self.K, x, params.BA_DISTANCE_TH, int(F / 4) + 1)
-            x = self._levenberg_marquardt(x, solver, max_iters, ftol)
+            if device_loop:
+                try:
+                    if solver.O:
+                        x, self.last_stats = solver.solve(x, max_iters, ftol, 1e-3, stop_on_flat_reject)
+                finally:
+                    solver.close()
+            else:
+                x = self._levenberg_marquardt(x, solver, max_iters, ftol, stop_on_flat_reject)
         cams = x[:6 * F].reshape(F, 6)
         adjusted_M = np.zeros(M.shape)
         adjusted_M[:, :, 3] = cams[:, 3:]
@@ -136,10 +152,10 @@ class BundleAdjustment:
             adjusted_M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
         return adjusted_M, x[6 * F:].reshape(landmarks.shape).copy()
 
-    def _levenberg_marquardt(self, x, solver, max_iters, ftol):
-        """LM loop on the device-resident solver: every trial step (Schur complement, reduced solve,
-        back-substitution, re-linearisation) runs on the GPU; the host only compares two costs.
-        Closes the solver."""
+    def _levenberg_marquardt(self, x, solver, max_iters, ftol, stop_on_flat_reject=True):
+        """The LM loop with the decisions on the host (what vo_ba_solve runs on the device): every trial step (Schur
+        complement, reduced solve, back-substitution, re-linearisation) runs on the GPU, the host compares two costs
+        after each.  Closes the solver."""
         try:
             if solver.O == 0:
                 return x
@@ -161,7 +177,7 @@ class BundleAdjustment:
                     # the step along (nearly) the same direction, so nothing above the tolerance is left to gain.
                     # (The frozen cameras' observations count in the cost but not in the Jacobian -- the reference's
                     # sparsity pattern --, so the model's minimum is not exactly the cost's and such endings are common.)
-                    if usable and abs(cost_new - cost) < ftol * cost:
+                    if stop_on_flat_reject and usable and abs(cost_new - cost) < ftol * cost:
                         converged = True
                         break
                     lam *= 10
