@@ -47,6 +47,15 @@ int vo_sync(vo_ctx *ctx);
 int vo_timer_start(vo_ctx *ctx);
 int vo_timer_stop_ms(vo_ctx *ctx, float *ms);  /* records stop, synchronises, returns elapsed */
 
+/* Plain device buffers on the context's GPU, for callers that bring no tensor library (the reference keeps every
+ * array in numpy; the pipeline's bootstrap keeps SIFT descriptors on the GPU between extraction and matching --
+ * vo_pipeline/bootstrap.py:179-191 -- without crossing the bus twice).  vo_dev_upload is asynchronous on the
+ * context's stream and the host array is free on return; vo_dev_free and vo_dev_download synchronise the stream. */
+int vo_dev_alloc(vo_ctx *ctx, size_t bytes, void **out);
+int vo_dev_free(vo_ctx *ctx, void *ptr);
+int vo_dev_upload(vo_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int vo_dev_download(vo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
 /* ---- image pyramid ------------------------------------------------------
  * Replaces the pyramid that cv.calcOpticalFlowPyrLK builds internally for both
  * images on every call (vo_pipeline/poseEstimation.py:122-132): Gaussian 5-tap
@@ -451,7 +460,9 @@ int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, int width, in
  * (pt.x, pt.y, size, angle in degrees, response, octave packed as octave | layer << 8 | offset << 16),
  * sorted and de-duplicated as cv2 returns them; descriptors (max_keypoints, 128) float32 with byte values
  * (follows `mem`; may be NULL: detect only).  *n_keypoints (host) = keypoints found; only the first
- * max_keypoints are written.  Synchronises the stream (keypoints are ordered on the host).
+ * max_keypoints are written (a caller that wants them all calls again with that much room).  The library's own room
+ * for extrema and raw keypoints grows with the image that needs it: as cv2's nfeatures = 0, there is no bound but
+ * memory.  Synchronises the stream (keypoints are ordered on the host).
  *
  * vo_sift_scale_space_image (tests / debugging): builds the scale space of the image and copies one Gaussian
  * (which = 0, index 0 .. layers + 2) or difference (which = 1, index 0 .. layers + 1) image of `octave` to the

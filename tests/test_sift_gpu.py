@@ -114,3 +114,49 @@ def test_get_kp_mirror_and_sift_bootstrap(ctx, oracle):
     np.testing.assert_allclose(b.T[:3, :3], rel[:3, :3], atol=2e-2)
     t_true = rel[:3, 3] / np.linalg.norm(rel[:3, 3])
     assert b.T[:3, 3] @ t_true > 0.97
+
+
+def test_buffers_grow_with_the_image(oracle, monkeypatch):
+    """A frame with more scale-space extrema or raw keypoints than the library's room (set tiny here): the room grows to what the counters ask for and the passes run again -- same result as
+    the checker, no bound but memory, as cv2's nfeatures = 0.  More keypoints than the caller's first room: the
+    Python call asks again for all of them instead of clipping the right-hand side of the image."""
+    from visual_odometry_amd import hip
+    monkeypatch.setenv("VO_SIFT_CAND_CAP", "1024")        # 16 per list
+    monkeypatch.setenv("VO_SIFT_KP_CAP", "512")           # 8 per list
+    small = hip.Context(0)                                # a fresh context reads the starting room
+    try:
+        img = synth.frame_pair((120, 160), seed=3)[0]
+        rk, rd = oracle.sift(img)
+        assert len(rk) > 500                              # ~13 per keypoint list, more extrema than that per candidate list
+        kp, des = hip.sift_detect_compute(small, img)
+        _same(kp, des, rk, rd)
+        kp, des = hip.sift_detect_compute(small, img, max_keypoints=100)      # an explicit bound: the first rows
+        _same(kp, des, rk[:100], rd[:100])
+        monkeypatch.setattr(hip, "SIFT_FIRST_ROOM", 300, raising=False)
+        kp, des = hip.sift_detect_compute(small, img, device_descriptors=True)
+        assert isinstance(des, hip.DeviceArray) and des.shape == (len(rk), 128)
+        _same(kp, des.numpy(), rk, rd)
+        # a smaller image afterwards, in the grown buffers
+        img2 = synth.frame_pair((60, 80), seed=1)[0]
+        _same(*hip.sift_detect_compute(small, img2), *oracle.sift(img2))
+    finally:
+        small.close()
+
+
+def test_device_descriptors_feed_the_matcher(ctx, oracle):
+    """Descriptors left on the GPU in library-owned memory (no tensor library involved) and matched there equal
+    the host route."""
+    from visual_odometry_amd import hip
+    a, b, _ = synth.frame_pair((200, 260), seed=9, max_shift=4.0)
+    k0, d0 = hip.sift_detect_compute(ctx, a)
+    k1, d1 = hip.sift_detect_compute(ctx, b)
+    g0 = hip.sift_detect_compute(ctx, a, device_descriptors=True)[1]
+    g1 = hip.sift_detect_compute(ctx, b, device_descriptors=True)[1]
+    assert np.array_equal(g0.numpy(), d0) and np.array_equal(g1.numpy(), d1)
+    ref = hip.knn_match2(ctx, d0, d1, 0.8)
+    got = hip.knn_match2(ctx, g0, g1, 0.8)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    assert np.array_equal(g0[:10].numpy(), d0[:10])
+    with pytest.raises(IndexError):
+        g0[5:]

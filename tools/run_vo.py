@@ -148,6 +148,7 @@ def main():
         timed(bam.BundleAdjustment, "bundle_adjustment", "bundle_adjustment")
         timed(_hip.BaSolver, "__init__", "BaSolver.__init__")
         timed(_hip.BaSolver, "try_step", "BaSolver.try_step")
+        timed(_hip.BaSolver, "solve", "BaSolver.solve")
         timed(_hip.BaSolver, "linearize", "BaSolver.linearize")
         timed(_hip.BaSolver, "params", "BaSolver.params")
         timed(_hip, "ba_residual", "hip.ba_residual")

@@ -34,6 +34,10 @@ SIGNATURES = {
     "vo_ctx_create": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.POINTER(c_vp)]),
     "vo_ctx_destroy": (ctypes.c_int, [c_vp]),
     "vo_sync": (ctypes.c_int, [c_vp]),
+    "vo_dev_alloc": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
+    "vo_dev_free": (ctypes.c_int, [c_vp, c_vp]),
+    "vo_dev_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t]),
+    "vo_dev_download": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t]),
     "vo_timer_start": (ctypes.c_int, [c_vp]),
     "vo_timer_stop_ms": (ctypes.c_int, [c_vp, c_f32p]),
     "vo_pyr_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -2684,3 +2684,12 @@ extern "C" int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, in
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_ba(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)ba_cam_sum_kernel));
+    return VO_OK;
+}

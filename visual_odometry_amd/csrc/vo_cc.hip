@@ -462,3 +462,12 @@ extern "C" int vo_harris_corners(vo_ctx *ctx, const uint8_t *img, int height, in
     *n_corners = n_comp + 1;
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_cc(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)cc_init_kernel));
+    return VO_OK;
+}

@@ -31,6 +31,8 @@ void vo_set_error(const char *fmt, ...)
 extern "C" const char *vo_last_error(void) { return g_err; }
 extern "C" int vo_version(void) { return 100; }
 
+__global__ void copy_pinned_wide_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, unsigned n16);
+
 extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
 {
     VO_REQUIRE(out != nullptr, "vo_ctx_create: out is NULL");
@@ -49,6 +51,19 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
         std::lock_guard<std::mutex> lk(setup_mu);
         int rc = vo_klt_noalloc_setup(device);   // once per device, with that device current
         if (rc) return rc;
+        static bool loaded[64];
+        if (device < 64 && !loaded[device]) {
+            const char *lazy = getenv("VO_LAZY_CODE_LOADING");        // "1": leave code loading to the first launches
+            if (!(lazy && lazy[0] == '1')) {
+                int (*const loaders[])(void) = {vo_load_code_ba, vo_load_code_cc, vo_load_code_frame, vo_load_code_harris, vo_load_code_klt, vo_load_code_match, vo_load_code_pyramid, vo_load_code_score, vo_load_code_sift, vo_load_code_solvers, vo_load_code_subpix, vo_load_code_twoview};
+                for (auto fn : loaders)
+                    if ((rc = fn())) return rc;
+                // the copy kernels of this file, and the runtime's first-use set-up of page-locked memory and of a stream
+                hipFuncAttributes attr;
+                VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)copy_pinned_wide_kernel));
+            }
+            loaded[device] = true;
+        }
     }
     vo_ctx *c = new (std::nothrow) vo_ctx();
     if (!c) { vo_set_error("vo_ctx_create: out of host memory"); return VO_ENOMEM; }
@@ -108,6 +123,43 @@ extern "C" int vo_timer_stop_ms(vo_ctx *ctx, float *ms)
     VO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
     VO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     VO_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VO_OK;
+}
+
+// ---- plain device buffers for callers that bring no tensor library --------------------------------------
+extern "C" int vo_dev_alloc(vo_ctx *ctx, size_t bytes, void **out)
+{
+    VO_REQUIRE(ctx && out, "vo_dev_alloc: NULL argument");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) { vo_set_error("vo_dev_alloc: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return VO_ENOMEM; }
+    return VO_OK;
+}
+
+extern "C" int vo_dev_free(vo_ctx *ctx, void *ptr)
+{
+    VO_REQUIRE(ctx != nullptr, "vo_dev_free: ctx is NULL");
+    if (!ptr) return VO_OK;
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));       // queued work of this context may still use the buffer
+    VO_HIP_CHECK(hipFree(ptr));
+    return VO_OK;
+}
+
+extern "C" int vo_dev_upload(vo_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes)
+{
+    VO_REQUIRE(ctx && (bytes == 0 || (dev_dst && host_src)), "vo_dev_upload: NULL argument");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    return vo_upload(ctx, dev_dst, host_src, bytes);
+}
+
+extern "C" int vo_dev_download(vo_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    VO_REQUIRE(ctx && (bytes == 0 || (host_dst && dev_src)), "vo_dev_download: NULL argument");
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    VO_RESULT(ctx, host_dst, dev_src, bytes);
+    VO_RESULTS_FINISH(ctx);
     return VO_OK;
 }
 

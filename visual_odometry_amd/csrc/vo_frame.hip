@@ -788,3 +788,12 @@ extern "C" int vo_track_pnp_batch(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr 
     if (rc) return rc;
     return vo_track_pnp_batch_finish(ctx, rng_state, Rt_out, n_tracked, n_inliers, path);
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_frame(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)frame_prep_kernel));
+    return VO_OK;
+}

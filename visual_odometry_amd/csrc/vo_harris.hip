@@ -800,3 +800,12 @@ extern "C" int vo_harris_mask(vo_ctx *ctx, const uint8_t *img, int batch, int he
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_harris(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)harris_response_kernel));
+    return VO_OK;
+}

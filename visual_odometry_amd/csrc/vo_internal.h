@@ -61,6 +61,8 @@ struct vo_ctx {
     size_t ba_pool_bytes = 0;
     // device and page-locked state of vo_track_pnp_batch (vo_frame.hip), kept from call to call
     struct vo_frame_batch *fb = nullptr;
+    // vo_sift_detect_compute: room for scale-space extrema and raw keypoints (grown when an image overflows it)
+    int sift_cand_cap = 0, sift_kp_cap = 0;
     // vo_profile_tracker: event pair around the tracker launch of the next vo_track_pnp_batch_begin
     bool prof_tracker = false, prof_recorded = false;
     hipEvent_t prof0 = nullptr, prof1 = nullptr;
@@ -70,6 +72,22 @@ struct vo_ctx {
 void vo_frame_batch_free(vo_ctx *ctx);
 
 bool vo_ctx_is_live(const vo_ctx *ctx);
+
+// One per translation unit with kernels: asks the runtime for the attributes of one of the file's kernels, which
+// loads the file's device code on the current device.  vo_ctx_create calls them all the first time a device gets a
+// context, so that the tens of milliseconds of code loading are spent there and not inside the first frame.
+int vo_load_code_ba(void);
+int vo_load_code_cc(void);
+int vo_load_code_frame(void);
+int vo_load_code_harris(void);
+int vo_load_code_klt(void);
+int vo_load_code_match(void);
+int vo_load_code_pyramid(void);
+int vo_load_code_score(void);
+int vo_load_code_sift(void);
+int vo_load_code_solvers(void);
+int vo_load_code_subpix(void);
+int vo_load_code_twoview(void);
 
 // Reprojection test of solvePnPRansac's scoring: point i of pa (n,3) under the 3x4 model m against pb (n,2);
 // float64 in this order, the squared error compared in float32 (every kernel that scores PnP candidates uses it,

@@ -1092,3 +1092,12 @@ extern "C" int vo_klt_track_fb_noalloc(vo_ctx *ctx, const vo_pyr *prev, const vo
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_klt(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)klt_track_kernel));
+    return VO_OK;
+}

@@ -371,3 +371,12 @@ extern "C" int vo_knn_match2(vo_ctx *ctx, const float *des1, int n1, const float
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_match(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)desc_pack_kernel));
+    return VO_OK;
+}

@@ -328,3 +328,12 @@ extern "C" int vo_pyr_download(vo_ctx *ctx, const vo_pyr *pyr, int image, int le
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_pyramid(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)pyr_down_rows_kernel<8>));
+    return VO_OK;
+}

@@ -168,3 +168,12 @@ int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, c
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_score(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)score_kernel<true>));
+    return VO_OK;
+}

@@ -978,61 +978,90 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
 
     // candidates and raw keypoints: counters | candidates | keypoints (context slot 3)
     // counters (candidate lists | keypoint lists | keypoint total) | candidates | keypoint lists | keypoints joined
-    const int cand_cap = 1 << 19, kp_cap = 1 << 18;
+    // The room for both starts at half a million extrema and a quarter of a million raw keypoints (five times what a
+    // dense KITTI-sized texture yields) and belongs to the context: a frame that overflows one of the 64 lists of
+    // either kind -- the kernels keep counting past the end without writing there -- has the room grown to what the
+    // counters ask for and the detection passes run again (the scale space stays).  VO_SIFT_CAND_CAP / VO_SIFT_KP_CAP
+    // in the environment set the starting room (tests).
+    if (!ctx->sift_cand_cap) {
+        const char *e1 = getenv("VO_SIFT_CAND_CAP"), *e2 = getenv("VO_SIFT_KP_CAP");
+        ctx->sift_cand_cap = e1 && atoi(e1) >= SIFT_LISTS ? atoi(e1) / SIFT_LISTS * SIFT_LISTS : 1 << 19;
+        ctx->sift_kp_cap = e2 && atoi(e2) >= SIFT_LISTS ? atoi(e2) / SIFT_LISTS * SIFT_LISTS : 1 << 18;
+    }
     const size_t cnt_bytes = (size_t)(2 * SIFT_LISTS * SIFT_LIST_STRIDE + 64) * 4;
-    void *p;
-    if ((rc = vo_stage_reserve(ctx, 3, cnt_bytes + (size_t)cand_cap * sizeof(SiftCand) + 2 * (size_t)kp_cap * sizeof(vo_sift_keypoint), &p)))
-        return rc;
-    int *d_cnt = (int *)p, *d_kcnt = d_cnt + SIFT_LISTS * SIFT_LIST_STRIDE, *d_ktotal = d_kcnt + SIFT_LISTS * SIFT_LIST_STRIDE;
-    int *d_radius_hist = nullptr;       // SIFT_LISTS rows of SIFT_JOB_BINS counts behind the job arrays (rewritten whole by every call)
-    // descriptor jobs, unordered and ordered, for as many keypoints as the keypoint buffer holds (formed while the lists are joined)
     const bool describe = descriptors && max_keypoints > 0;
-    SiftJob *d_jobs = nullptr;
-    if (describe) {
-        void *q;
-        const size_t job_bytes = (2 * (size_t)kp_cap * sizeof(SiftJob) + 255) & ~(size_t)255;
-        if ((rc = vo_stage_reserve(ctx, 4, job_bytes + (size_t)SIFT_LISTS * SIFT_JOB_BINS * 4, &q))) return rc;
-        d_jobs = (SiftJob *)q;
-        d_radius_hist = (int *)((char *)q + job_bytes);
-    }
-    SiftCand *d_cand = (SiftCand *)((char *)p + cnt_bytes);
-    vo_sift_keypoint *d_klists = (vo_sift_keypoint *)((char *)p + cnt_bytes + (size_t)cand_cap * sizeof(SiftCand));
-    vo_sift_keypoint *d_kp = d_klists + kp_cap;
-    VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
     const int threshold = (int)floor(0.5 * contrast_threshold / n_octave_layers * 255);
-    for (int o = 0; o < O.n_oct; ++o) {
-        const int ow = O.w[o], oh = O.h[o];
-        if (ow <= 2 * SIFT_IMG_BORDER || oh <= 2 * SIFT_IMG_BORDER) continue;
-        hipLaunchKernelGGL(sift_extrema_kernel, dim3((ow - 2 * SIFT_IMG_BORDER + 63) / 64, (oh - 2 * SIFT_IMG_BORDER + 3) / 4, n_octave_layers),
-                           dim3(256), 0, ctx->stream, (const float *)(S.pool + O.dog_off[o]), (size_t)ow * oh, ow, oh, o, threshold,
-                           d_cand, d_cnt, cand_cap);
-    }
-    VO_HIP_CHECK(hipGetLastError());
+    int cand_cap = 0, kp_cap = 0;
+    int *d_cnt = nullptr, *d_kcnt = nullptr, *d_ktotal = nullptr, *d_radius_hist = nullptr;
+    SiftJob *d_jobs = nullptr;
+    SiftCand *d_cand = nullptr;
+    vo_sift_keypoint *d_klists = nullptr, *d_kp = nullptr;
     int h_cnt[2] = {0, 0};
-    {
+    void *p;
+    for (int attempt = 0;; ++attempt) {
+        VO_REQUIRE(attempt < 8, "vo_sift_detect_compute: the candidate buffers keep overflowing");
+        cand_cap = ctx->sift_cand_cap; kp_cap = ctx->sift_kp_cap;
+        if ((rc = vo_stage_reserve(ctx, 3, cnt_bytes + (size_t)cand_cap * sizeof(SiftCand) + 2 * (size_t)kp_cap * sizeof(vo_sift_keypoint), &p)))
+            return rc;
+        d_cnt = (int *)p; d_kcnt = d_cnt + SIFT_LISTS * SIFT_LIST_STRIDE; d_ktotal = d_kcnt + SIFT_LISTS * SIFT_LIST_STRIDE;
+        d_radius_hist = nullptr;       // SIFT_LISTS rows of SIFT_JOB_BINS counts behind the job arrays (rewritten whole by every call)
+        // descriptor jobs, unordered and ordered, for as many keypoints as the keypoint buffer holds (formed while the lists are joined)
+        if (describe) {
+            void *q;
+            const size_t job_bytes = (2 * (size_t)kp_cap * sizeof(SiftJob) + 255) & ~(size_t)255;
+            if ((rc = vo_stage_reserve(ctx, 4, job_bytes + (size_t)SIFT_LISTS * SIFT_JOB_BINS * 4, &q))) return rc;
+            d_jobs = (SiftJob *)q;
+            d_radius_hist = (int *)((char *)q + job_bytes);
+        }
+        d_cand = (SiftCand *)((char *)p + cnt_bytes);
+        d_klists = (vo_sift_keypoint *)((char *)p + cnt_bytes + (size_t)cand_cap * sizeof(SiftCand));
+        d_kp = d_klists + kp_cap;
+        VO_HIP_CHECK(hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
+        for (int o = 0; o < O.n_oct; ++o) {
+            const int ow = O.w[o], oh = O.h[o];
+            if (ow <= 2 * SIFT_IMG_BORDER || oh <= 2 * SIFT_IMG_BORDER) continue;
+            hipLaunchKernelGGL(sift_extrema_kernel, dim3((ow - 2 * SIFT_IMG_BORDER + 63) / 64, (oh - 2 * SIFT_IMG_BORDER + 3) / 4, n_octave_layers),
+                               dim3(256), 0, ctx->stream, (const float *)(S.pool + O.dog_off[o]), (size_t)ow * oh, ow, oh, o, threshold,
+                               d_cand, d_cnt, cand_cap);
+        }
+        VO_HIP_CHECK(hipGetLastError());
+        h_cnt[0] = h_cnt[1] = 0;
         int h_lists[SIFT_LISTS * SIFT_LIST_STRIDE];
         VO_RESULT(ctx, h_lists, d_cnt, sizeof(h_lists));
         VO_RESULTS_FINISH(ctx);
+        int longest = 0;
         for (int l = 0; l < SIFT_LISTS; ++l) {
             const int n = h_lists[l * SIFT_LIST_STRIDE];
-            if (n > cand_cap / SIFT_LISTS) {
-                vo_set_error("vo_sift_detect_compute: %d scale-space extrema in one of %d lists exceed its share of the candidate buffer (%d)",
-                             n, SIFT_LISTS, cand_cap / SIFT_LISTS);
-                return VO_ESTATE;
-            }
+            longest = n > longest ? n : longest;
             h_cnt[0] += n;
         }
+        if (longest > cand_cap / SIFT_LISTS) {
+            const int64_t want = ((int64_t)longest + longest / 4 + 64) * SIFT_LISTS;
+            VO_REQUIRE(want < (1ll << 30), "vo_sift_detect_compute: %d scale-space extrema in one of %d lists", longest, SIFT_LISTS);
+            ctx->sift_cand_cap = (int)want;
+            continue;
+        }
+        if (h_cnt[0] > 0) {
+            hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
+                               (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_klists, d_kcnt, kp_cap);
+            hipLaunchKernelGGL(sift_join_lists_kernel, dim3(SIFT_LISTS), dim3(256), 0, ctx->stream, (const vo_sift_keypoint *)d_klists,
+                               (const int *)d_kcnt, kp_cap, d_kp, d_ktotal, O, describe ? d_jobs + kp_cap : (SiftJob *)nullptr, d_radius_hist);
+            VO_HIP_CHECK(hipGetLastError());
+        }
+        VO_RESULT(ctx, h_cnt + 1, d_ktotal, 4);
+        VO_RESULTS_FINISH(ctx);
+        if (h_cnt[1] > kp_cap) {        // a keypoint list overflowed: its counter says by how much
+            VO_RESULT(ctx, h_lists, d_kcnt, sizeof(h_lists));
+            VO_RESULTS_FINISH(ctx);
+            longest = 0;
+            for (int l = 0; l < SIFT_LISTS; ++l) longest = h_lists[l * SIFT_LIST_STRIDE] > longest ? h_lists[l * SIFT_LIST_STRIDE] : longest;
+            const int64_t want = ((int64_t)longest + longest / 4 + 64) * SIFT_LISTS;
+            VO_REQUIRE(want < (1ll << 28) && want > kp_cap, "vo_sift_detect_compute: %d keypoints in one of %d lists", longest, SIFT_LISTS);
+            ctx->sift_kp_cap = (int)want;
+            continue;
+        }
+        break;
     }
-    if (h_cnt[0] > 0) {
-        hipLaunchKernelGGL(sift_refine_kernel, dim3(h_cnt[0]), dim3(64), 0, ctx->stream, (const float *)S.pool, O, (const SiftCand *)d_cand,
-                           (const int *)d_cnt, cand_cap, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_klists, d_kcnt, kp_cap);
-        hipLaunchKernelGGL(sift_join_lists_kernel, dim3(SIFT_LISTS), dim3(256), 0, ctx->stream, (const vo_sift_keypoint *)d_klists,
-                           (const int *)d_kcnt, kp_cap, d_kp, d_ktotal, O, describe ? d_jobs + kp_cap : (SiftJob *)nullptr, d_radius_hist);
-        VO_HIP_CHECK(hipGetLastError());
-    }
-    VO_RESULT(ctx, h_cnt + 1, d_ktotal, 4);
-    VO_RESULTS_FINISH(ctx);
-    if (h_cnt[1] > kp_cap) { vo_set_error("vo_sift_detect_compute: %d keypoints exceed the keypoint buffer (%d)", h_cnt[1], kp_cap); return VO_ESTATE; }
     const size_t n_raw = (size_t)h_cnt[1];
     if (n_raw == 0) { *n_keypoints = 0; return VO_OK; }
     // Everything the rest of the call needs, before anything is queued (growing a buffer waits for the device):
@@ -1131,5 +1160,14 @@ extern "C" int vo_sift_detect_compute(vo_ctx *ctx, const uint8_t *img, int heigh
         VO_HIP_CHECK(hipMemcpyAsync(descriptors, d_desc, n_out * 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
     // the page-locked row order must stay untouched until the kernel has read its copy: wait in both memory modes
     VO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_sift(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)sift_upsample_kernel));
     return VO_OK;
 }

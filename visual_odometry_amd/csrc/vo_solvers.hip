@@ -420,3 +420,12 @@ extern "C" int vo_seven_point_solve(vo_ctx *ctx, const float *m1, const float *m
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_solvers(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)p3p_kernel));
+    return VO_OK;
+}

@@ -156,3 +156,12 @@ extern "C" int vo_corner_subpix(vo_ctx *ctx, const uint8_t *img, int height, int
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_subpix(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)corner_subpix_kernel));
+    return VO_OK;
+}

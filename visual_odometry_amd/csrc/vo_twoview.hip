@@ -212,3 +212,12 @@ extern "C" int vo_cheirality_vote(vo_ctx *ctx, const float *pts1, const float *p
     }
     return VO_OK;
 }
+
+// Makes the runtime load this file's device code now (vo_ctx_create calls it once per device) instead of at the
+// first launch of one of its kernels.
+int vo_load_code_twoview(void)
+{
+    hipFuncAttributes attr;
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)triangulate_kernel));
+    return VO_OK;
+}

@@ -23,9 +23,72 @@ def _is_torch(x) -> bool:
 def _ptr(x):
     if x is None:
         return None
+    if isinstance(x, DeviceArray):
+        return ctypes.c_void_p(x.ptr)
     if _is_torch(x):
         return ctypes.c_void_p(x.data_ptr())
     return ctypes.c_void_p(x.ctypes.data)
+
+
+class DeviceArray:
+    """A C-contiguous array in the memory of a context's GPU, owned by the library (vo_dev_alloc): what the pipeline
+    keeps on the device between two library calls without bringing in a tensor library.  `[:n]` is a view of the
+    leading rows; `numpy()` copies out (synchronises the context's stream)."""
+
+    def __init__(self, ctx: "Context", shape, dtype, _base=None):
+        self.ctx, self.shape, self.dtype = ctx, tuple(int(v) for v in shape), np.dtype(dtype)
+        self._base = _base
+        if _base is None:
+            h = ctypes.c_void_p()
+            check(ctx.lib.vo_dev_alloc(ctx.handle, max(self.nbytes, 16), ctypes.byref(h)), "vo_dev_alloc")
+            self.ptr = h.value
+            _live_objects.add(self)
+        else:
+            self.ptr = _base.ptr
+
+    @classmethod
+    def from_numpy(cls, ctx: "Context", a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = cls(ctx, a.shape, a.dtype)
+        check(ctx.lib.vo_dev_upload(ctx.handle, ctypes.c_void_p(d.ptr), ctypes.c_void_p(a.ctypes.data), a.nbytes), "vo_dev_upload")
+        return d
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def __getitem__(self, key) -> "DeviceArray":
+        if not (isinstance(key, slice) and key.start in (None, 0) and key.step in (None, 1)):
+            raise IndexError("DeviceArray: only leading-row views a[:n]")
+        n = self.shape[0] if key.stop is None else max(0, min(int(key.stop), self.shape[0]))
+        return DeviceArray(self.ctx, (n,) + self.shape[1:], self.dtype, _base=self._base if self._base is not None else self)
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        if out.nbytes:
+            check(self.ctx.lib.vo_dev_download(self.ctx.handle, ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(self.ptr), out.nbytes),
+                  "vo_dev_download")
+        return out
+
+    def close(self) -> None:
+        if self._base is None and self.ptr:
+            self.ctx.lib.vo_dev_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -89,7 +152,7 @@ def _shutdown():
     """Destroy pyramids and solvers before contexts, while the HIP runtime is still up."""
     objs = list(_live_objects)
     for o in objs:
-        if isinstance(o, (Pyramid, BaSolver)):
+        if isinstance(o, (Pyramid, BaSolver, DeviceArray)):
             o.close()
     for o in objs:
         if isinstance(o, Context):
@@ -639,30 +702,49 @@ SIFT_KEYPOINT = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.floa
                           ("response", np.float32), ("octave", np.int32)])
 
 
+SIFT_FIRST_ROOM = 65536          # keypoints a first sift_detect_compute attempt has room for
+
+
 def sift_detect_compute(ctx: Context, img, n_octave_layers: int = 4, contrast_threshold: float = 0.03, edge_threshold: float = 10.0,
-                        sigma: float = 1.6, max_keypoints: int = 65536, want_descriptors: bool = True):
+                        sigma: float = 1.6, max_keypoints: Optional[int] = None, want_descriptors: bool = True,
+                        device_descriptors: bool = False):
     """SIFT keypoints and descriptors of one grayscale uint8 image, as cv.SIFT_create(0, layers, contrast, edge,
     sigma).detectAndCompute(img, None) -> (keypoints: structured numpy array SIFT_KEYPOINT, descriptors (n,128) float32
-    -- numpy for a numpy image, a GPU tensor for a GPU image -- or None)."""
+    -- numpy for a numpy image, a GPU tensor for a GPU image, a DeviceArray for a numpy image with device_descriptors
+    -- or None).  max_keypoints = None returns all keypoints, as cv2 does (an image with more than the room of the
+    first attempt is described again with the room it asked for); a number keeps the first that many in cv2's order
+    (x-major: the left of the image)."""
     n = ctypes.c_int32()
-    kp = np.empty(int(max_keypoints), SIFT_KEYPOINT)
-    if _is_torch(img):
-        import torch
-        if img.dtype != torch.uint8 or img.dim() != 2 or img.stride(1) != 1:
-            raise ValueError("sift_detect_compute: device image must be a 2-D uint8 tensor with unit pixel stride")
-        H, W = img.shape
-        des = torch.empty((int(max_keypoints), 128), dtype=torch.float32, device=img.device) if want_descriptors else None
-        rs, mem = img.stride(0), VO_MEM_DEVICE
-    else:
-        img = np.ascontiguousarray(img, np.uint8)
-        if img.ndim != 2:
-            raise ValueError("sift_detect_compute: image must be 2-D")
-        H, W = img.shape
-        des = np.empty((int(max_keypoints), 128), np.float32) if want_descriptors else None
-        rs, mem = W, VO_MEM_HOST
-    check(ctx.lib.vo_sift_detect_compute(ctx.handle, _ptr(img), int(H), int(W), int(rs), int(n_octave_layers),
-                                         float(contrast_threshold), float(edge_threshold), float(sigma), _ptr(kp), _ptr(des),
-                                         int(max_keypoints), ctypes.byref(n), mem), "vo_sift_detect_compute")
+    truncate = max_keypoints is not None
+    if max_keypoints is None:
+        max_keypoints = SIFT_FIRST_ROOM
+    while True:
+        kp = np.empty(int(max_keypoints), SIFT_KEYPOINT)
+        if _is_torch(img):
+            import torch
+            if img.dtype != torch.uint8 or img.dim() != 2 or img.stride(1) != 1:
+                raise ValueError("sift_detect_compute: device image must be a 2-D uint8 tensor with unit pixel stride")
+            H, W = img.shape
+            des = torch.empty((int(max_keypoints), 128), dtype=torch.float32, device=img.device) if want_descriptors else None
+            src, rs, mem = img, img.stride(0), VO_MEM_DEVICE
+        else:
+            img = np.ascontiguousarray(img, np.uint8)
+            if img.ndim != 2:
+                raise ValueError("sift_detect_compute: image must be 2-D")
+            H, W = img.shape
+            if device_descriptors and want_descriptors:
+                src = DeviceArray.from_numpy(ctx, img)
+                des = DeviceArray(ctx, (int(max_keypoints), 128), np.float32)
+                rs, mem = W, VO_MEM_DEVICE
+            else:
+                des = np.empty((int(max_keypoints), 128), np.float32) if want_descriptors else None
+                src, rs, mem = img, W, VO_MEM_HOST
+        check(ctx.lib.vo_sift_detect_compute(ctx.handle, _ptr(src), int(H), int(W), int(rs), int(n_octave_layers),
+                                             float(contrast_threshold), float(edge_threshold), float(sigma), _ptr(kp), _ptr(des),
+                                             int(max_keypoints), ctypes.byref(n), mem), "vo_sift_detect_compute")
+        if truncate or int(n.value) <= int(max_keypoints):
+            break
+        max_keypoints = int(n.value)          # more keypoints than room: again, with room for all of them
     m = min(int(n.value), int(max_keypoints))
     return kp[:m], (des[:m] if want_descriptors else None)
 
@@ -684,6 +766,21 @@ def knn_match2(ctx: Context, des1, des2, ratio: float = 0.8):
     """Two nearest rows of des2 (n2,128) for every row of des1 (n1,128), exhaustive float32 L2 search.
     Returns (idx (n1,2) int32, dist (n1,2) float32, keep (n1) uint8); keep = dist[:,0] < ratio * dist[:,1].
     A missing neighbour is index -1 at distance inf."""
+    if isinstance(des1, DeviceArray) or isinstance(des2, DeviceArray):
+        # library-owned device descriptors: the three small results come back as numpy arrays
+        if not (isinstance(des1, DeviceArray) and isinstance(des2, DeviceArray)) or des1.dtype != np.float32 or des2.dtype != np.float32:
+            raise ValueError("knn_match2: device descriptors must both be float32 DeviceArrays")
+        if des1.ndim != 2 or des2.ndim != 2 or des1.shape[1] != des2.shape[1]:
+            raise ValueError("knn_match2: descriptors must be (n1,d) and (n2,d), got %s and %s" % (des1.shape, des2.shape))
+        n1, n2, dim = des1.shape[0], des2.shape[0], des1.shape[1]
+        # one buffer: idx (n1,2) int32 | dist (n1,2) float32 | keep (n1) uint8
+        buf = DeviceArray(ctx, (n1 * 17 + 16,), np.uint8)
+        check(ctx.lib.vo_knn_match2(ctx.handle, _ptr(des1), n1, _ptr(des2), n2, dim, float(ratio), ctypes.c_void_p(buf.ptr),
+                                    ctypes.c_void_p(buf.ptr + n1 * 8), ctypes.c_void_p(buf.ptr + n1 * 16), VO_MEM_DEVICE), "vo_knn_match2")
+        raw = buf.numpy()
+        buf.close()
+        return (raw[:n1 * 8].view(np.int32).reshape(n1, 2), raw[n1 * 8:n1 * 16].view(np.float32).reshape(n1, 2),
+                raw[n1 * 16:n1 * 17].copy())
     if _is_torch(des1):
         import torch
         if not _is_torch(des2) or des1.dtype != torch.float32 or des2.dtype != torch.float32:

@@ -36,6 +36,8 @@ class _DescriptorRows:
     def numpy(self) -> np.ndarray:
         if isinstance(self.source, np.ndarray):
             return np.asarray(self.source, np.float32)[self.rows]
+        if isinstance(self.source, hip.DeviceArray):
+            return self.source.numpy()[self.rows]
         import torch
         rows = torch.from_numpy(np.ascontiguousarray(self.rows, dtype=np.int64)).to(self.source.device)
         return self.source[rows].cpu().numpy()
@@ -107,7 +109,21 @@ class BootstrapInitializer:
         kp0, kp1 = self._keypoint_array(kp0), self._keypoint_array(kp1)
         self.kps = kp1
         matcher = FeatureMatcher(MatcherType.FLANN, k=2, matching_threshold=params.MATCHING_THRESHOLD)
+        on_torch = not isinstance(des0, (np.ndarray, hip.DeviceArray)) and hasattr(des0, "is_cuda")
+        if on_torch:
+            # the caller's tensors were written on torch's current stream, the library works on its context's stream:
+            # order the two by waiting on both sides of the call
+            import torch
+            torch.cuda.current_stream(des0.device).synchronize()
         idx, _, keep = matcher.match_arrays(des0, des1)
+        if on_torch:
+            _runtime.context().sync()
+        if isinstance(des0, hip.DeviceArray):
+            # descriptors in library-owned device memory: the (small) match arrays are numpy, the rows stay where they are
+            q = np.nonzero(keep)[0]
+            t = idx[q, 0]
+            logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
+            return kp0[q], kp1[t], _DescriptorRows(des0, q), _DescriptorRows(des1, t)
         if not isinstance(des0, np.ndarray) and hasattr(des0, "is_cuda"):
             # descriptors on the GPU: only the matched rows come back
             import torch

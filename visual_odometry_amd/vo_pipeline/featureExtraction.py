@@ -45,21 +45,17 @@ class FeatureExtractor:
     def sift_arrays(cls, img: np.ndarray, device_descriptors: bool = False) -> Tuple[np.ndarray, Any]:
         """SIFT on the GPU -> (keypoints as a structured array (x, y, size, angle, response, octave), descriptors
         (n, 128) float32): the array form of get_kp, without one Python object per keypoint.
-        device_descriptors: leave the descriptors on the GPU (a torch tensor) for a matcher that takes them there --
-        10 MB per 20 000 keypoints that need not cross the bus twice; falls back to numpy when torch has no GPU."""
+        device_descriptors: leave the descriptors on the GPU (a hip.DeviceArray, library-owned memory on the
+        context's stream) for a matcher that takes them there -- 10 MB per 20 000 keypoints that need not cross the
+        bus twice."""
         img = np.ascontiguousarray(img, dtype=np.uint8)
-        if device_descriptors:
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    return hip.sift_detect_compute(_runtime.context(), torch.from_numpy(img).cuda(), **cls.SIFT_ARGS)
-            except ImportError:
-                pass
-        return hip.sift_detect_compute(_runtime.context(), img, **cls.SIFT_ARGS)
+        return hip.sift_detect_compute(_runtime.context(), img, device_descriptors=device_descriptors, **cls.SIFT_ARGS)
 
     def get_kp(self, img: np.ndarray) -> Tuple[List[Any], np.ndarray]:
-        """Keypoints and (num_keypoints, 128) float32 descriptors of img (featureExtraction.py:28-35):
-        cv.SIFT_create(0, 4, 0.03, 10, 1.6).detectAndCompute(img, None), computed by vo_sift_detect_compute."""
+        """Keypoints and (num_keypoints, 128) float32 descriptors of img (featureExtraction.py:28-35), computed by
+        vo_sift_detect_compute: the algorithm of cv.SIFT_create(0, 4, 0.03, 10, 1.6).detectAndCompute(img, None) as
+        OpenCV 4.5.4 publishes it, bit-identical to this build's CPU restatement of it; against cv2 itself the
+        result is unpinned (cv2 is not installed where this was built, and the reference ships no SIFT vectors)."""
         kp, des = self.extractor(img)
         return [KeyPoint(k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"]) for k in kp], des
 
