@@ -39,9 +39,18 @@ class DeviceArray:
         self.ctx, self.shape, self.dtype = ctx, tuple(int(v) for v in shape), np.dtype(dtype)
         self._base = _base
         if _base is None:
-            h = ctypes.c_void_p()
-            check(ctx.lib.vo_dev_alloc(ctx.handle, max(self.nbytes, 16), ctypes.byref(h)), "vo_dev_alloc")
-            self.ptr = h.value
+            # Buffers go back to a per-context pool of power-of-two sizes when they are closed and are handed out again
+            # from there: a 30 MB descriptor matrix per bootstrap image would otherwise cost an allocation and -- worse
+            # -- a free that waits for the device, at every keyframe.  Work on the context's stream is ordered, so a
+            # reused buffer needs no synchronisation.
+            self._room = 1 << max(8, (max(self.nbytes, 1) - 1).bit_length())
+            free = ctx._dev_pool.get(self._room)
+            if free:
+                self.ptr = free.pop()
+            else:
+                h = ctypes.c_void_p()
+                check(ctx.lib.vo_dev_alloc(ctx.handle, self._room, ctypes.byref(h)), "vo_dev_alloc")
+                self.ptr = h.value
             _live_objects.add(self)
         else:
             self.ptr = _base.ptr
@@ -79,7 +88,8 @@ class DeviceArray:
 
     def close(self) -> None:
         if self._base is None and self.ptr:
-            self.ctx.lib.vo_dev_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            if self.ctx.handle:
+                self.ctx._dev_pool.setdefault(self._room, []).append(self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -100,6 +110,7 @@ class Context:
         check(self.lib.vo_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(h)), "vo_ctx_create")
         self.handle = h
         self.device = int(device)
+        self._dev_pool = {}          # room in bytes -> device pointers of closed DeviceArrays, ready for reuse
         _live_objects.add(self)
 
     @classmethod
@@ -130,6 +141,10 @@ class Context:
 
     def close(self) -> None:
         if self.handle:
+            for ptrs in self._dev_pool.values():
+                for ptr in ptrs:
+                    self.lib.vo_dev_free(self.handle, ctypes.c_void_p(ptr))
+            self._dev_pool.clear()
             self.lib.vo_ctx_destroy(self.handle)
             self.handle = None
 

@@ -46,6 +46,14 @@ def baseline_uncertainty(T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray) 
     return float(np.linalg.norm(T1_inv[:3, 3] - T0_inv[:3, 3]) / np.mean(d))
 
 
+def _tracked_frame_rows(status: np.ndarray, inlier_mask: np.ndarray):
+    """One pass over what the fused tracked-frame call returns: (rows with status 1 as a boolean mask, their number,
+    the INPUT rows of the PnP inliers in ascending order).  Equals filter_tracked followed by np.unique(inliers) and the
+    gathers through them, without building the intermediate arrays."""
+    keep = np.asarray(status).ravel() == 1
+    return keep, int(np.count_nonzero(keep)), np.flatnonzero(inlier_mask)
+
+
 def assemble_ba_window(poses: Sequence[np.ndarray], per_frame: Sequence[Tuple[np.ndarray, np.ndarray]],
                        landmark_of_traj: Dict[int, np.ndarray]):
     """Build the BA arrays for a window of frames (continuousVO.py:287-313).
@@ -208,8 +216,16 @@ class ContinuousVO:
                                                                                 reuse_pyramids=True)
         else:
             tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints, reuse_pyramids=True)
-        tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
-                                                                      prev_trajectories)
+        if self.fused_step and T is not None:
+            # the call's inlier mask is over the input rows already: no compaction of points and trajectory ids just to
+            # index them again through the inlier list
+            keep, n_tracked, rows = _tracked_frame_rows(status, self.poseEstimator.last_inlier_mask)
+            tracked_landmarks = prev_landmarks[keep]
+        else:
+            rows = None
+            tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
+                                                                          prev_trajectories)
+            n_tracked = tracked_pts.shape[0]
         if tracked_landmarks.shape[0] > 5:
             if not self.fused_step:
                 T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
@@ -220,19 +236,22 @@ class ContinuousVO:
             prev_keyframe = self.keyframes[-1]
             T = self._bootstrap(prev_keyframe, frame_idx, img, world_transform=self.frame_queue.queue[-1].pose)
             self.bootstrap_idx.append(frame_idx)
-            frame_state = FrameState(frame_idx, img, T, tracked_kps=tracked_pts.shape[0], is_key=True)
+            frame_state = FrameState(frame_idx, img, T, tracked_kps=n_tracked, is_key=True)
             self.frame_queue.add(frame_state)
             self.keyframes.append(frame_state)
             return
 
-        keep = np.unique(inliers.ravel())       # ascending: the order the reference visits them in
-        store.tracked_to_many(trajectories[keep], frame_idx, tracked_pts[keep], T)
+        if rows is not None:
+            store.tracked_to_many(prev_trajectories[rows], frame_idx, tracked_pts[rows], T)
+        else:
+            keep = np.unique(inliers.ravel())       # ascending: the order the reference visits them in
+            store.tracked_to_many(trajectories[keep], frame_idx, tracked_pts[keep], T)
 
         is_key = False
         prev_keyframe = self.keyframes[-2] if len(self.keyframes) >= 2 else self.keyframes[-1]
         uncertainty = self._baseline_uncertainty(prev_keyframe.pose, T, tracked_landmarks)
         log.info("%d: tracked_pts: %5d, inlier_ratio: %.2f, baseline uncertainty: %.2f", frame_idx,
-                 tracked_pts.shape[0], ratio, uncertainty)
+                 n_tracked, ratio, uncertainty)
         if uncertainty > params.MAX_BASELINE_UNCERTAINTY or ratio < params.MIN_INLIER_RATIO:
             is_key = True
             self._bundle_adjustment(frame_idx, T)
@@ -241,7 +260,7 @@ class ContinuousVO:
                                 world_transform=T if self.rescale_bootstrap else prev_keyframe.pose)
             self.bootstrap_idx.append(frame_idx)
 
-        frame_state = FrameState(frame_idx, img, T, tracked_kps=tracked_pts.shape[0], is_key=is_key)
+        frame_state = FrameState(frame_idx, img, T, tracked_kps=n_tracked, is_key=is_key)
         self.frame_queue.add(frame_state)
         if is_key:
             self.keyframes.append(frame_state)

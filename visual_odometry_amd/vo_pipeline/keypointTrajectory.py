@@ -66,6 +66,7 @@ class _TrajToLandmark:
 
     def __init__(self):
         self._g = _Growable(0, np.int64)
+        self.version = 0          # bumped when an existing trajectory's landmark changes (frames cache their lookups)
 
     def _grow_to(self, n: int) -> None:
         if n > self._g.n:
@@ -83,6 +84,7 @@ class _TrajToLandmark:
     def __setitem__(self, traj_idx, landmark_id) -> None:
         self._grow_to(int(traj_idx) + 1)
         self._g.view[int(traj_idx)] = int(landmark_id)
+        self.version += 1
 
     def lookup(self, traj_ids: np.ndarray) -> np.ndarray:
         """Landmark id per trajectory id, -1 where unset."""
@@ -97,10 +99,12 @@ class _FrameObservations:
     def __init__(self):
         self._ids: List[np.ndarray] = []
         self._pts: List[np.ndarray] = []
+        self.served = None        # what at_frame last returned for this frame, with the landmark-map version it saw
 
     def add(self, ids: np.ndarray, pts: np.ndarray) -> None:
         self._ids.append(ids)
         self._pts.append(pts)
+        self.served = None
 
     def _consolidate(self) -> None:
         if len(self._ids) > 1:
@@ -219,13 +223,20 @@ class KeypointTrajectories:
         for callers that only want the observations (the bundle-adjustment window)."""
         assert frame_idx in self.on_frame, f"frame_idx {frame_idx} needs to have keypoints associated with it"
         obs = self.on_frame[frame_idx]
-        ids = obs.ids
-        lid = self.traj2landmark.lookup(ids)
-        keep = lid >= 0
-        if keep.all():
-            pts, kept = obs.pts.astype(np.float32), ids.astype(np.int32)
+        # a frame is asked for once when it is tracked from and again by every bundle-adjustment window that reaches
+        # back to it: the converted arrays are kept until the frame gets observations or a landmark link changes
+        # (callers treat them as read-only)
+        if obs.served is not None and obs.served[0] == self.traj2landmark.version:
+            _, pts, kept, lid = obs.served
         else:
-            pts, kept, lid = obs.pts[keep].astype(np.float32), ids[keep].astype(np.int32), lid[keep]
+            ids = obs.ids
+            lid = self.traj2landmark.lookup(ids)
+            keep = lid >= 0
+            if keep.all():
+                pts, kept = obs.pts.astype(np.float32), ids.astype(np.int32)
+            else:
+                pts, kept, lid = obs.pts[keep].astype(np.float32), ids[keep].astype(np.int32), lid[keep]
+            obs.served = (self.traj2landmark.version, pts, kept, lid)
         if not with_landmarks:
             return pts, kept, None
         return pts, kept, self.landmarks.array[lid].astype(np.float32).reshape(-1, 3)

@@ -92,6 +92,8 @@ class PoseEstimation:
         except Exception:
             _runtime.forget_pyramids()          # the deferred pyramid may not have been built
             raise
+        self.last_inlier_mask = mask        # over the INPUT rows (0 where a row was not tracked): what a caller that
+                                            # keeps its own row bookkeeping reads instead of re-deriving it from `inliers`
         if Rt is None:
             return out, st.reshape(n, 1), None, np.zeros((0, 1), np.int32)
         M = np.eye(4)
