@@ -44,3 +44,46 @@ def test_single_rank_dry_run_needs_no_launcher():
     assert p.returncode == 0, p.stderr[-2000:]
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["gather_ok"]
+
+
+def test_self_launch_eight_ranks():
+    """The scaling run's own shape, `--gpus 8`: eight self-launched ranks meet, shard 16 streams (stream s on rank
+    s mod 8), gather them in global order, and rank 0 reports every rank's elapsed time."""
+    p = _run("--gpus", "8", "--streams-per-gpu", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["gather_ok"] and rec["gathered_shape"][0] == 16
+    assert len(rec["per_rank_elapsed_s"]) == 8 and max(rec["per_rank_elapsed_s"]) == rec["max_elapsed_s"]
+
+
+def test_stream_cache_round_trip(tmp_path):
+    """A stream synthesised once is loaded from the cache directory afterwards, bit for bit (ranks of later runs on
+    one machine skip the seconds of scipy before the first barrier); a damaged file is synthesised again."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    old = (bench.H, bench.W, bench.N_KP)
+    bench.H, bench.W, bench.N_KP = 48, 64, 20          # a small frame: the protocol, not the size
+    try:
+        a = bench.make_streams([3, 11], 2, cache_dir=str(tmp_path))
+        files = sorted(os.listdir(tmp_path))
+        assert len(files) == 2 and all(f.endswith(".npz") for f in files)
+        b = bench.make_streams([3, 11], 2, cache_dir=str(tmp_path))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        with open(os.path.join(tmp_path, files[0]), "wb") as f:
+            f.write(b"not an archive")
+        c = bench.make_streams([3, 11], 2, cache_dir=str(tmp_path))
+        for x, y in zip(a, c):
+            assert np.array_equal(x, y)
+        # the true flow: a keypoint of frame 0 lies at moved[1] in frame 1 (ring-wise), within the synthetic motion's range
+        frames, pts, moved = a
+        assert moved.shape == (2, 2, 20, 2) and np.abs(moved[1] - pts).max() < 8.0
+        X, poses = bench.make_landmarks([3, 11], moved, 0.0)
+        K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]])
+        proj = (K @ (poses[1, 0, :, :3] @ X[1, 0].T.astype(np.float64) + poses[1, 0, :, 3:])).T
+        assert np.abs(proj[:, :2] / proj[:, 2:] - moved[1, 0]).max() < 1e-2       # landmarks project onto the flow (float32 storage)
+    finally:
+        bench.H, bench.W, bench.N_KP = old
