@@ -113,14 +113,16 @@ int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next,
                     float lambda, float *next_pts, uint8_t *mask, int mem);
 
 /* vo_klt_track_fb_noalloc has no counterpart in the reference.  It is vo_klt_track_fb for callers
- * that cannot allocate device memory while they run -- code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc: same kernels, same results, device pointers only
+ * that cannot allocate device memory while they run -- tight serving loops, harnesses that forbid
+ * hipMalloc: same kernels, same results, device pointers only
  * (VO_MEM_DEVICE semantics, asynchronous on the context's stream), and the intermediate results
  * (back-tracked points, the two status arrays: 10 bytes per keypoint) live in a fixed array in
  * device memory of VO_KLT_FB_NOALLOC_MAX_KEYPOINTS entries (2.5 MiB per GPU, held until the process
  * ends) that vo_ctx_create locates once per device.  The call allocates and frees nothing.
- * batch * n beyond the maximum -> VO_EINVAL.  All calls on one GPU share the array: calls that
- * overlap on one GPU (several contexts or streams) race; serialise them.
+ * batch * n beyond the maximum -> VO_EINVAL.  All calls on one GPU share the array: calls on one
+ * stream are ordered; a call from another stream (another context) while the previous call's
+ * kernels are still running is refused with VO_ESTATE -- wait for that stream first.  Host threads
+ * that call at the same moment must serialise themselves.
  */
 #define VO_KLT_FB_NOALLOC_MAX_KEYPOINTS 262144
 int vo_klt_track_fb_noalloc(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *next, const float *prev_pts, int n,

@@ -61,3 +61,38 @@ def test_noalloc_refuses_sizes_beyond_its_scratch(ctx):
     rc = _fb_noalloc(ctx, p0, p0, pts, 0.1, out, mask)
     assert rc == -1 and b"exceed the fixed scratch" in ctx.lib.vo_last_error()
     assert _fb_noalloc(ctx, p0, p0, pts[:, :0], 0.1, out, mask) == 0         # empty input is a no-op
+
+
+def test_noalloc_refuses_an_overlapping_call_from_another_stream(ctx):
+    """All calls on a GPU share the scratch array: a call on another stream while the previous call's kernels are
+    still running is refused; once that stream has been waited for, it goes through with the same result."""
+    import torch
+    dev = torch.device("cuda", 0)
+    shape, batch, n = (376, 1241), 16, 4000
+    pairs = [synth.frame_pair(shape, seed=40 + b % 2) for b in range(2)]
+    img0 = torch.from_numpy(np.stack([pairs[b % 2][0] for b in range(batch)])).to(dev)
+    img1 = torch.from_numpy(np.stack([pairs[b % 2][1] for b in range(batch)])).to(dev)
+    pts = torch.from_numpy(np.stack([synth.uniform_keypoints(shape, n, seed=b, margin=3) for b in range(batch)])).to(dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s1):
+        c1 = hip.Context.from_torch(0)
+    with torch.cuda.stream(s2):
+        c2 = hip.Context.from_torch(0)
+    torch.cuda.synchronize()
+    p0, p1 = hip.Pyramid(c1, batch, *shape).build(img0), hip.Pyramid(c1, batch, *shape).build(img1)
+    q0, q1 = hip.Pyramid(c2, batch, *shape).build(img0), hip.Pyramid(c2, batch, *shape).build(img1)
+    torch.cuda.synchronize()
+    out1, out2 = torch.empty_like(pts), torch.empty_like(pts)
+    m1 = torch.empty((batch, n), dtype=torch.uint8, device=dev)
+    m2 = torch.empty_like(m1)
+    assert _fb_noalloc(c1, p0, p1, pts, 0.1, out1, m1) == 0              # ~0.3 ms of kernels queued on stream 1
+    assert _fb_noalloc(c1, p0, p1, pts, 0.1, out1, m1) == 0              # the same stream again: ordered, accepted
+    rc = _fb_noalloc(c2, q0, q1, pts, 0.1, out2, m2)                      # stream 2 while stream 1 still runs
+    assert rc == -4 and b"still in use" in c2.lib.vo_last_error()
+    c1.sync()
+    assert _fb_noalloc(c2, q0, q1, pts, 0.1, out2, m2) == 0, c2.lib.vo_last_error()
+    c2.sync()
+    assert torch.equal(out1, out2) and torch.equal(m1, m2)
+    for o in (p0, p1, q0, q1):
+        o.close()
+    c1.close(); c2.close()

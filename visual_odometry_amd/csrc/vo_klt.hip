@@ -1027,14 +1027,16 @@ extern "C" int vo_klt_track_fb(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr *ne
 }
 
 // ---------------------------------------------------------------------------
-// Forward-backward tracking for callers that cannot allocate (HIP graph capture, tight
-// serving loops): the same three launches as vo_klt_track_fb, with the intermediate
+// Forward-backward tracking for callers that cannot allocate (tight serving loops,
+// harnesses that forbid hipMalloc): the same three launches as vo_klt_track_fb, with the intermediate
 // results -- back-tracked points and the two status arrays, 10 bytes per keypoint -- in
 // a fixed device array instead of the context's growable staging buffers.
 // Every GPU holds its own copy of the array at its own address; the address is looked up
 // once per device (vo_klt_noalloc_setup, called by vo_ctx_create with that device
 // current) and only that pointer is ever handed to kernels.  Calls on one GPU share the
-// array: calls that overlap on one GPU (two contexts, two streams) race.  Nothing in it
+// array: a call from another stream while the previous call's kernels are still running is
+// refused (VO_ESTATE; calls on one stream are ordered anyway).  The check is made by the
+// calling host thread: two host threads calling at once are the caller's to serialise.  Nothing in it
 // has to start at zero -- each call's kernels write every entry they later read.
 // ---------------------------------------------------------------------------
 #define FB_MAX_KP VO_KLT_FB_NOALLOC_MAX_KEYPOINTS
@@ -1046,6 +1048,12 @@ static __device__ __align__(256) unsigned char scratch[FB_SCRATCH_BYTES];
 
 #define FB_MAX_DEVICES 64
 static unsigned char *g_scratch_ptr[FB_MAX_DEVICES];   // per device: address of that GPU's copy of `scratch`
+// Who used a device's array last: an event recorded behind that call's kernels (created with the address, once per
+// device) and the stream it ran on.  A call from another stream while that event is still pending would write
+// the array under the earlier call's kernels; it is refused instead.
+static hipEvent_t g_scratch_done[FB_MAX_DEVICES];
+static hipStream_t g_scratch_stream[FB_MAX_DEVICES];
+static bool g_scratch_used[FB_MAX_DEVICES];
 
 int vo_klt_noalloc_setup(int device)
 {
@@ -1054,6 +1062,7 @@ int vo_klt_noalloc_setup(int device)
     void *p = nullptr;
     VO_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));   // the current device's copy
     VO_REQUIRE(p != nullptr, "vo_klt_noalloc_setup: no device address for the scratch array");
+    VO_HIP_CHECK(hipEventCreateWithFlags(&g_scratch_done[device], hipEventDisableTiming));
     g_scratch_ptr[device] = (unsigned char *)p;
     return VO_OK;
 }
@@ -1072,6 +1081,16 @@ extern "C" int vo_klt_track_fb_noalloc(vo_ctx *ctx, const vo_pyr *prev, const vo
                "vo_klt_track_fb_noalloc: scratch of device %d was not set up", ctx->device);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     unsigned char *base = g_scratch_ptr[ctx->device];
+    if (g_scratch_used[ctx->device] && g_scratch_stream[ctx->device] != ctx->stream) {
+        // same stream: ordered behind the earlier call.  Another stream: only once that call's kernels are through.
+        const hipError_t q = hipEventQuery(g_scratch_done[ctx->device]);
+        if (q == hipErrorNotReady) {
+            vo_set_error("vo_klt_track_fb_noalloc: the scratch array of device %d is still in use by a call on another stream; "
+                         "serialise the calls (or use vo_klt_track_fb)", ctx->device);
+            return VO_ESTATE;
+        }
+        VO_HIP_CHECK(q);
+    }
     float *d_back = (float *)(base + FB_OFF_BACK);
     uint8_t *d_sf = base + FB_OFF_SF, *d_sb = base + FB_OFF_SB;
     int rc;
@@ -1090,6 +1109,9 @@ extern "C" int vo_klt_track_fb_noalloc(vo_ctx *ctx, const vo_pyr *prev, const vo
     hipLaunchKernelGGL(klt_fb_check_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev_pts,
                        (const float *)d_back, (const uint8_t *)d_sf, (const uint8_t *)d_sb, lambda, next_pts, mask, cnt);
     VO_HIP_CHECK(hipGetLastError());
+    VO_HIP_CHECK(hipEventRecord(g_scratch_done[ctx->device], ctx->stream));
+    g_scratch_stream[ctx->device] = ctx->stream;
+    g_scratch_used[ctx->device] = true;
     return VO_OK;
 }
 
