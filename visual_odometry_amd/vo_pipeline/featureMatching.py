@@ -40,13 +40,9 @@ class FeatureMatcher:
                  nbr_tress: int = 5,
                  nbr_search: int = 50,
                  matching_threshold: float = 0.8):
-        """
-        :param matcher_type:        matcher algorithm used
-        :param k:                   Number of Nearest Neighbors (1 or 2)
-        :param nbr_tress:           number of trees (unused: the search is exhaustive)
-        :param nbr_search:          number of tree traversals (unused)
-        :param matching_threshold   discard all matches where first and second match are too close together
-        """
+        """k: neighbours per query (1 or 2).  matching_threshold: the ratio of the ratio test (a match is kept when its
+        distance is below this fraction of the runner-up's).  nbr_tress, nbr_search: the kd-tree settings of the
+        reference's FLANN matcher, accepted and ignored -- the search here is exhaustive."""
         self.k = k
         self.nbr_tress = nbr_tress
         self.nbr_search = nbr_search

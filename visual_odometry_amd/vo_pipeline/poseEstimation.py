@@ -34,7 +34,10 @@ class PoseEstimation:
         self.KLT_tracker = TrackPoints(params.KLT_RADIUS, params.KLT_N_ITERS, params.KLT_LAMBDA)
 
     def get_method(self):
-        # every method funnels into the same minimal solver (P3P on 3 points + 1 to disambiguate)
+        # Every method funnels into the same minimal solver: P3P on three points, a fourth to pick the root.  For P3P and
+        # AP3P that is what cv.solvePnPRansac samples too; for DEFAULT (SOLVEPNP_ITERATIVE, reference
+        # poseEstimation.py:41-42) OpenCV draws five-point samples and solves them iteratively -- a deliberate
+        # difference here, off the active path (ContinuousVO constructs its estimator with AlgoMethod.P3P).
         self.algo_method = {AlgoMethod.DEFAULT: "ITERATIVE", AlgoMethod.P3P: "P3P",
                             AlgoMethod.AP3P: "AP3P"}[self.algo_method_type]
 
@@ -103,9 +106,8 @@ class PoseEstimation:
 
     def match_key_points(self, pointcloud: np.ndarray, img0: np.ndarray, img1: np.ndarray) -> np.ndarray:
         """use_KLT: track self.prev_kpts from img0 to img1 and keep the found ones.  Otherwise the
-        reference's descriptor branch (poseEstimation.py:96-112): descriptors of both images are matched
-        on the GPU; they come from FeatureExtractor.get_kp, which this build leaves to the caller
-        (it raises NotImplementedError unless overridden with a SIFT implementation)."""
+        reference's descriptor branch (poseEstimation.py:96-112): SIFT keypoints and descriptors of both images
+        (FeatureExtractor.get_kp, on the GPU) matched on the GPU; the matched keypoints of img1 come back."""
         if self.use_KLT:
             pts1, st = self.KLT(img0, img1, self.prev_kpts)
             found = st == 1
