@@ -111,7 +111,7 @@ def main():
 
         PoseEstimation.KLT = staticmethod(klt_rec)
         PoseEstimation.PnP = pnp_rec
-    parts = {}
+    parts, windows = {}, []       # windows: (cameras, landmarks, observations, trial steps, accepted steps) per BA call
     if a.profile:
         from visual_odometry_amd.vo_pipeline import continuousVO as cvo, keypointTrajectory as kt
         from visual_odometry_amd.vo_pipeline.poseEstimation import PoseEstimation as PE
@@ -147,6 +147,16 @@ def main():
         timed(cvo.ContinuousVO, "_ba_window", "_ba_window")
         timed(bam.BundleAdjustment, "bundle_adjustment", "bundle_adjustment")
         timed(_hip.BaSolver, "__init__", "BaSolver.__init__")
+        timed(_hip.BaSolver, "filtered", "BaSolver.filtered", static=True)      # a bound classmethod: no self to pass on
+        ba_run = bam.BundleAdjustment.bundle_adjustment
+
+        def ba_recorded(self, M, landmarks, ci, *args, **kw):
+            out = ba_run(self, M, landmarks, ci, *args, **kw)
+            st = getattr(self, "last_stats", None) or {}
+            windows.append([int(M.shape[0]), int(landmarks.shape[0]), int(np.asarray(ci).size), int(st.get("trial_steps", 0)),
+                            int(st.get("accepted", 0))])
+            return out
+        bam.BundleAdjustment.bundle_adjustment = ba_recorded
         timed(_hip.BaSolver, "try_step", "BaSolver.try_step")
         timed(_hip.BaSolver, "solve", "BaSolver.solve")
         timed(_hip.BaSolver, "linearize", "BaSolver.linearize")
@@ -183,7 +193,7 @@ def main():
                       "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
                       **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()},
                           "total_ms_of_parts": {k: float(np.sum(v) * 1e3) for k, v in parts.items()},
-                          "calls_of_parts": {k: len(v) for k, v in parts.items()}} if parts else {})}))
+                          "calls_of_parts": {k: len(v) for k, v in parts.items()}, "ba_windows": windows} if parts else {})}))
 
 
 if __name__ == "__main__":

@@ -196,7 +196,11 @@ int vo_stage_reserve(vo_ctx *ctx, int slot, size_t bytes, void **out)
             b.ptr = nullptr;
             b.cap = 0;
         }
-        size_t cap = bytes + bytes / 2;
+        // a frame loop's requests grow slowly (a bundle-adjustment window gains a few thousand observations per
+        // keyframe): double, and never start below 16 MB, so that a run regrows a handful of times in all -- each
+        // regrowth is a stream synchronisation, a hipFree and a hipMalloc, about a millisecond
+        size_t cap = 2 * bytes;
+        if (cap < ((size_t)16 << 20)) cap = (size_t)16 << 20;
         hipError_t e = hipMalloc(&b.ptr, cap);
         if (e != hipSuccess) {
             vo_set_error("device allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
@@ -218,7 +222,8 @@ int vo_pinned_reserve(vo_ctx *ctx, size_t bytes, void **out)
             ctx->pinned = nullptr;
             ctx->pinned_cap = 0;
         }
-        const size_t cap = bytes + bytes / 2;
+        size_t cap = 2 * bytes;                                  // grows as the stage buffers do
+        if (cap < ((size_t)4 << 20)) cap = (size_t)4 << 20;
         hipError_t e = hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault);
         if (e != hipSuccess) {
             vo_set_error("page-locked host allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
