@@ -91,6 +91,45 @@ def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis, solve, monkeypatch)
     solver.close()
 
 
+# The Schur complement of a system kept in global memory: a block pair per lane (the default when every landmark's
+# observations ascend in camera), a landmark per wavefront ("strips"), sums straight into global memory ("global").
+# Windows shaped like the frame loop's (runs of neighbouring cameras, a few long tracks), a landmark seen twice by one
+# camera, and observations in no camera order (which the pair kernel does not take: the solver falls back by itself).
+@pytest.mark.parametrize("case", ["window", "window_wide", "twice", "shuffled"])
+@pytest.mark.parametrize("schur", ["", "strips", "global"])
+def test_schur_variants_match_dense_numpy(oracle, ctx, case, schur, monkeypatch):
+    from visual_odometry_amd import hip
+    if schur:
+        monkeypatch.setenv("VO_BA_SCHUR", schur)
+    if case == "window_wide":
+        pb = synth.ba_window_problem(F=90, births_every=6, per_birth=40, survive=0.93, seed=4)
+    else:
+        pb = synth.ba_window_problem(F=40, births_every=5, per_birth=50, survive=0.88, seed=3)
+    F, P, K = pb["F"], pb["P"], pb["K"]
+    ci, pi, obs, x = pb["ci"], pb["pi"], pb["obs"].astype(np.float64), pb["x"]
+    start = _start(F, ci)
+    if case == "twice":
+        # every tenth observation with Jacobian rows once more, a pixel away, right behind the original
+        again = np.arange(start, ci.size)[::10]
+        order = np.sort(np.concatenate([np.arange(ci.size), again]), kind="stable")
+        ci, pi, obs = ci[order], pi[order], obs[order]
+        obs[np.flatnonzero(np.diff(order) == 0) + 1] += 1.0
+    if case == "shuffled":
+        order = np.random.default_rng(0).permutation(ci.size)
+        ci, pi, obs = ci[order], pi[order], obs[order]
+        start = 0
+    ne = oracle.ba_normal_eq(x, F, P, ci, pi, obs, K, start)
+    solver = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+    solver.linearize(x)
+    for lam in (1e-3, 10.0):
+        want = numpy_lm_step(ne, x, F, P, ci, pi, lam)
+        _, solved = solver.try_step(lam)
+        assert solved
+        got = solver.params(candidate=True)
+        assert np.abs(got - want).max() <= 1e-7 * max(np.abs(want - x).max(), 1e-12) + 1e-12
+    solver.close()
+
+
 def test_device_inputs_and_unseen_landmarks(oracle, ctx):
     import torch
     from visual_odometry_amd import hip

@@ -1002,6 +1002,10 @@ struct vo_ba {
     int cam_first = 0;     // cameras below this one have no observation with Jacobian rows
     bool panels = false;   // factorise with one launch per panel (ba_solve_panel_kernel)
     double *Lf = nullptr, *zf = nullptr, *dinv = nullptr;      // its factor, eliminated right-hand side, 1 / pivots
+    int *pcam = nullptr;   // camera of every entry of the landmark-major lists (pobs)
+    int2 *bcam = nullptr;  // (lowest, highest) camera in the lists of landmarks 64 b .. 64 b + 63; (INT_MAX, -1) when they are empty
+    bool lists_sorted = false;   // cameras ascend along every landmark's list (observations sorted by camera)
+    bool pairs = false;    // strip-wise Schur complement with a block pair per lane (ba_schur_pairs_kernel)
     int n_strips = 0;    // strips of the strip-wise Schur complement of such a system (0: global atomics)
     int strip_budget = 0;  // doubles of LDS a strip may take
     size_t strip_lds = 0;
@@ -1215,6 +1219,176 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_strip_kernel(int n, in
             unsafeAtomicAdd(S + (size_t)(6 * c0 + r) * n + colbase + c, v);
         }
     }
+}
+
+// Dp^-1 of every landmark for the damping of this trial step (identity for a landmark without Jacobian rows).
+__global__ __launch_bounds__(256) void ba_point_inverse_kernel(int P, const double *__restrict__ Hpp, double lambda,
+                                                               double *__restrict__ Dpinv, const BaCtl *__restrict__ ctl = nullptr)
+{
+    if (ctl) { if (ctl->done) return; lambda = ctl->lambda; }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    double inv[9];
+    bool dead;
+    damped_point_inverse(Hpp + 9 * (int64_t)p, lambda, inv, dead);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Dpinv[9 * (int64_t)p + k] = inv[k];
+}
+
+// First index of the ascending array v[0..k) whose value is not below key.
+__device__ __forceinline__ int ba_lower_bound(const int *__restrict__ v, int k, int key)
+{
+    int lo = 0, hi = k;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// The strip-wise Schur complement with a block pair per lane.  ba_schur_strip_kernel gives a landmark to a wavefront,
+// which walks the landmark's observations one after the other through scalar loads: three quarters of its cycles are
+// waits for those loads, and a landmark seen by sixty cameras keeps its wavefront a hundred times as long as one seen
+// by six.  Here the unit of work is a pair (a, b <= a) of observations of one landmark -- one 6 x 6 block
+// E_a Dp^-1 E_b^T of the reduced system: a wavefront takes 64 landmarks, a lane each, finds by two binary searches
+// which of its landmark's observations fall on the strip's cameras (the lists ascend in camera), a prefix sum numbers
+// the strip's pairs of all 64, and the lanes then take 64 pairs at a time whatever landmark they belong to: every lane
+// loads its two blocks and the landmark's inverse itself, so all of a wavefront's loads are in flight together, and
+// adds its 36 products (21 for a pair with itself) to the strip's tile in LDS.  The right-hand side rows of the strip
+// come from the pairs (a, a).  Needs the lists' cameras ascending (pcam), the cameras a block of 64 landmarks spans
+// (bcam: first, last) and Dp^-1 from ba_point_inverse_kernel.
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(int n, int P, int F, int cam_first, int budget,
+                                                                       const int *__restrict__ pptr, const int *__restrict__ pobs,
+                                                                       const int *__restrict__ pcam, const int2 *__restrict__ bcam,
+                                                                       const double *__restrict__ Hcp,
+                                                                       const double *__restrict__ g, const double *__restrict__ Dpinv,
+                                                                       double *__restrict__ S, double *__restrict__ rhs,
+                                                                       const BaCtl *__restrict__ ctl = nullptr)
+{
+    extern __shared__ double sl[];
+    if (ctl && ctl->done) return;
+    int c0, c1;                                                            // cameras of this strip
+    if (!ba_strip_bounds(cam_first, F, budget, blockIdx.y, c0, c1)) return;
+    const int colbase = 6 * cam_first, rows = 6 * (c1 - c0), cols = 6 * c1 - colbase;
+    double *rl = sl + (size_t)rows * cols;                                 // the strip's rows of the right-hand side
+    for (int i = threadIdx.x; i < rows * cols + rows; i += SCHUR_THREADS) sl[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int waves = SCHUR_THREADS / 64;
+    const int nblk = (P + 63) / 64, wave = threadIdx.x >> 6;
+    // A workgroup takes a block of 64 landmarks at a time and its wavefronts share the block's pairs: landmarks that
+    // start at one keyframe are neighbours in number and see the same cameras, so a strip's pairs sit in a few dozen
+    // blocks, and with a block per wavefront those few wavefronts did the whole strip.  Most blocks hold nothing for a
+    // strip; the range of cameras a block's landmarks see (bcam) tells without touching their lists.
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int2 span = bcam[blk];
+        if (span.y < c0 || span.x >= c1) continue;
+        const int p = blk * 64 + lane;
+        int o0 = 0, k = 0;
+        if (p < P) { o0 = pptr[p]; k = pptr[p + 1] - o0; }
+        int a_lo = 0, a_hi = 0;                                            // the landmark's observations on the strip's cameras
+        if (k > 0 && pcam[o0 + k - 1] >= c0 && pcam[o0] < c1) {
+            a_lo = ba_lower_bound(pcam + o0, k, c0);
+            a_hi = ba_lower_bound(pcam + o0, k, c1);
+        }
+        // pairs (a, b) with a_lo <= a < a_hi, b <= a, numbered row after row: pair r of the whole triangle is
+        // (a, r - a (a + 1) / 2) with a the last row that starts at or before r
+        const int tlo = a_lo * (a_lo + 1) / 2;
+        const int cnt = a_hi * (a_hi + 1) / 2 - tlo;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int excl = incl - cnt;
+        const int total = __shfl(incl, 63);
+        for (int q = 64 * wave; q < total; q += 64 * waves) {
+            const int e = q + lane;
+            // the landmark of pair e: the last lane whose first pair is at or before e (lanes without pairs share
+            // their successor's start, so the last of equals is the one that owns it)
+            int L = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int cand = L + step;
+                const int first_of = __shfl(excl, cand & 63);
+                if (cand < 64 && first_of <= e) L = cand;
+            }
+            const int base = __shfl(excl, L), tl = __shfl(tlo, L), oL = __shfl(o0, L);
+            if (e < total) {
+                const int r = e - base + tl;
+                int a = (int)((sqrtf(8.0f * (float)r + 1.0f) - 1.0f) * 0.5f);
+                while (a * (a + 1) / 2 > r) --a;
+                while ((a + 1) * (a + 2) / 2 <= r) ++a;
+                const int b = r - a * (a + 1) / 2;
+                const int oa = pobs[oL + a], ob = pobs[oL + b], ca = pcam[oL + a], cb = pcam[oL + b];
+                const int64_t pL = (int64_t)blk * 64 + L;
+                double inv[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) inv[t] = Dpinv[9 * pL + t];
+                // an observation's block is 144 bytes at a multiple of 144: 16-byte loads
+                const double2 *y2 = (const double2 *)(Hcp + 18 * (int64_t)ob);
+                double yv[18];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { const double2 two = y2[t]; yv[2 * t] = two.x; yv[2 * t + 1] = two.y; }
+                double W[6][3];                                            // Dp^-1 E_b^T, a column of three per row j of E_b
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double y0 = yv[3 * j], y1 = yv[3 * j + 1], y2_ = yv[3 * j + 2];
+                    W[j][0] = inv[0] * y0 + inv[1] * y1 + inv[2] * y2_;
+                    W[j][1] = inv[3] * y0 + inv[4] * y1 + inv[5] * y2_;
+                    W[j][2] = inv[6] * y0 + inv[7] * y1 + inv[8] * y2_;
+                }
+                const bool same = a == b, diag = ca == cb;
+                double u0 = 0, u1 = 0, u2 = 0;
+                if (same) {
+                    const double *gp = g + 6 * (int64_t)F + 3 * pL;
+                    u0 = inv[0] * gp[0] + inv[1] * gp[1] + inv[2] * gp[2];
+                    u1 = inv[3] * gp[0] + inv[4] * gp[1] + inv[5] * gp[2];
+                    u2 = inv[6] * gp[0] + inv[7] * gp[1] + inv[8] * gp[2];
+                }
+                const double2 *x2 = (const double2 *)(Hcp + 18 * (int64_t)oa);
+                const int row0 = 6 * (ca - c0);
+                double *tile = sl + (size_t)row0 * cols + 6 * cb - colbase;
+#pragma unroll
+                for (int i2 = 0; i2 < 3; ++i2) {                           // two rows of E_a at a time: three 16-byte loads
+                    const double2 xa = x2[3 * i2], xb = x2[3 * i2 + 1], xc = x2[3 * i2 + 2];
+                    const double xr[2][3] = {{xa.x, xa.y, xb.x}, {xb.y, xc.x, xc.y}};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = 2 * i2 + h;
+                        const double x0 = xr[h][0], x1 = xr[h][1], x2_ = xr[h][2];
+                        if (same) unsafeAtomicAdd(rl + row0 + i, x0 * u0 + x1 * u1 + x2_ * u2);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            double v = x0 * W[j][0] + x1 * W[j][1] + x2_ * W[j][2];
+                            if (v == 0.0) continue;
+                            if (!diag) unsafeAtomicAdd(tile + (size_t)i * cols + j, -v);
+                            else if (same) {
+                                if (i >= j) unsafeAtomicAdd(tile + (size_t)i * cols + j, -v);    // the block is symmetric: its lower half
+                            } else {
+                                // two observations of the landmark by one camera: the block and its transpose both fall
+                                // on the diagonal block, of which the lower half is kept
+                                if (i == j) v += v;
+                                unsafeAtomicAdd(tile + (size_t)(i > j ? i : j) * cols + (i > j ? j : i), -v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * cols; i += SCHUR_THREADS) {
+        const double v = sl[i];
+        if (v != 0.0) {
+            const int r = i / cols, c = i - r * cols;
+            unsafeAtomicAdd(S + (size_t)(6 * c0 + r) * n + colbase + c, v);
+        }
+    }
+    for (int i = threadIdx.x; i < rows; i += SCHUR_THREADS)
+        if (rl[i] != 0.0) unsafeAtomicAdd(rhs + 6 * c0 + i, rl[i]);
 }
 
 // Adds the damped camera blocks, then solves S dc = rhs - g_c in one workgroup by a
@@ -2020,7 +2194,7 @@ static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **o
     size_t tot = 0;
     auto take = [&](size_t bytes) { size_t at = tot; tot += (bytes + 255) / 256 * 256; return at; };
     const size_t o_ci = take(Oz * 8), o_pi = take(Oz * 8), o_cam = take(Oz * 4), o_pptr = take(((size_t)P + 1) * 4),
-                 o_pobs = take(Oz * 4), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
+                 o_pobs = take(Oz * 4), o_pcam = take(Oz * 4), o_bcam = take(((size_t)P / 64 + 1) * 8), o_flag = take(4), o_obs = take(Oz * 16), o_r = take(Oz * 16), o_jp = take(Oz * 48), o_rep = take(((size_t)BA_REPLICAS * F * 42 + BA_COST_SLOTS) * 8),
                  o_dpi = take((size_t)P * 72), o_S = take(n * n * 8), o_rhs = take(n * 8), o_dc = take(n * 8),
                  o_Lf = take(n * n * 8), o_zf = take(n * 8), o_dinv = take(n * 8), o_ctl = take(sizeof(BaCtl));
     size_t o_x[2], o_cost[2], o_Hcc[2], o_Hpp[2], o_Hcp[2], o_g[2];
@@ -2062,7 +2236,7 @@ static int ba_alloc(vo_ctx *ctx, int F, int P, int O, const double *K, vo_ba **o
     }
     char *b = ba->pool;
     ba->ci = (int64_t *)(b + o_ci); ba->pi = (int64_t *)(b + o_pi); ba->cam32 = (int *)(b + o_cam);
-    ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->flag = (int *)(b + o_flag);
+    ba->pptr = (int *)(b + o_pptr); ba->pobs = (int *)(b + o_pobs); ba->pcam = (int *)(b + o_pcam); ba->bcam = (int2 *)(b + o_bcam); ba->flag = (int *)(b + o_flag);
     ba->obs = (double *)(b + o_obs); ba->r = (double *)(b + o_r); ba->Jp = (double *)(b + o_jp); ba->cam_rep = (double *)(b + o_rep); ba->Dpinv = (double *)(b + o_dpi);
     ba->S = (double *)(b + o_S); ba->rhs = (double *)(b + o_rhs); ba->dc = (double *)(b + o_dc);
     ba->Lf = (double *)(b + o_Lf); ba->zf = (double *)(b + o_zf); ba->dinv = (double *)(b + o_dinv);
@@ -2128,7 +2302,7 @@ static void ba_configure(vo_ba *ba)
         // strips of the Schur complement: as many cameras' rows as fit in LDS beside nothing else
         // strips of the Schur complement: LDS for one camera's rows over the whole live width at least
         const size_t live = n - 6 * (size_t)cam_first;
-        size_t sbudget = 150 * 1024 / 8;
+        size_t sbudget = (150 * 1024 - 8 * n) / 8;              // beside the tile: the strip's rows of the right-hand side
         if (sbudget < 6 * live) sbudget = 0;
         int strips = 0, sc0, sc1;
         while (sbudget && ba_strip_bounds(cam_first, F, (int)sbudget, strips, sc0, sc1)) ++strips;
@@ -2137,6 +2311,9 @@ static void ba_configure(vo_ba *ba)
             ba->n_strips = strips;
             ba->strip_budget = (int)sbudget;
             ba->strip_lds = sbudget * 8;
+            ba->pairs = ba->lists_sorted &&
+                        hipFuncSetAttribute((const void *)ba_schur_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(sbudget * 8 + 8 * n)) == hipSuccess;
         }
         (void)hipGetLastError();
         ba->panels = ba->solve_w > 0;
@@ -2145,6 +2322,7 @@ static void ba_configure(vo_ba *ba)
         if (env && env[0] == 'b') ba->panels = false;     // "blocked": the blocked factorisation in one workgroup
         const char *env2 = getenv("VO_BA_SCHUR");         // "global": sums straight into global memory
         if (env2 && env2[0] == 'g') ba->n_strips = 0;
+        if (env2 && env2[0] == 's') ba->pairs = false;    // "strips": a landmark per wavefront (ba_schur_strip_kernel)
     }
 }
 
@@ -2213,9 +2391,25 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             free(fill);
         }
     }
+    // the camera of every list entry, and whether the cameras ascend along every list
+    int *pcam = (int *)malloc(((size_t)O + 1) * 4);
+    const size_t nblk64 = (size_t)P / 64 + 1;
+    int *bcam = (int *)malloc(nblk64 * 8);
+    bool sorted = true;
+    if (rc == VO_OK && (!pcam || !bcam)) { rc = VO_ENOMEM; vo_set_error("vo_ba_create: out of host memory"); }
+    if (rc == VO_OK) {
+        for (size_t b = 0; b < nblk64; ++b) { bcam[2 * b] = 0x7fffffff; bcam[2 * b + 1] = -1; }
+        for (int p = 0; p < P; ++p)
+            for (int e = pptr[p]; e < pptr[p + 1]; ++e) {
+                const int c = pcam[e] = cam32[pobs[e]];
+                if (e > pptr[p] && c < pcam[e - 1]) sorted = false;
+                if (c < bcam[2 * (p / 64)]) bcam[2 * (p / 64)] = c;
+                if (c > bcam[2 * (p / 64) + 1]) bcam[2 * (p / 64) + 1] = c;
+            }
+    }
     if (rc == VO_OK) rc = ba_alloc(ctx, F, P, O, K, &ba);
     if (rc == VO_OK) {
-        ba->obs_start = obs_start; ba->cam_first = cam_first;
+        ba->obs_start = obs_start; ba->cam_first = cam_first; ba->lists_sorted = sorted;
         const hipMemcpyKind kind = mem == VO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
         hipError_t e = hipSuccess;
         if (O) {
@@ -2223,8 +2417,10 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
             if (e == hipSuccess) e = hipMemcpy(ba->pi, spi, (size_t)O * 8, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(ba->cam32, cam32, (size_t)O * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(ba->pobs, pobs, (size_t)O * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(ba->pcam, pcam, (size_t)O * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(ba->obs, obs, (size_t)O * 16, kind);
         }
+        if (e == hipSuccess) e = hipMemcpy(ba->bcam, bcam, nblk64 * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(ba->pptr, pptr, ((size_t)P + 1) * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             vo_set_error("vo_ba_create: upload failed: %s", hipGetErrorString(e));
@@ -2232,7 +2428,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
         }
     }
     if (ba) ba_configure(ba);
-    free(hci); free(hpi); free(cam32); free(pptr); free(pobs);
+    free(hci); free(hpi); free(cam32); free(pptr); free(pobs); free(pcam); free(bcam);
     *out = ba;
     return rc;
 }
@@ -2245,7 +2441,7 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
 // flags, an exclusive scan, a stable compaction straight into the solver's arrays, and the landmark-major lists of
 // the kept observations with Jacobian rows (count per landmark, scan, fill, each list sorted by observation index
 // so that the sums that walk them are the same in every run and equal to those of host-built lists).
-struct BaMeta { int kept, frozen, cam_first, bad; };
+struct BaMeta { int kept, frozen, cam_first, bad, unsorted; };
 
 __global__ __launch_bounds__(256) void ba_keep_kernel(const double *__restrict__ r, const int64_t *__restrict__ ci,
                                                       const int64_t *__restrict__ pi, int O, int F, int P, double max_sq,
@@ -2336,6 +2532,33 @@ __global__ __launch_bounds__(256) void ba_lists_sort_kernel(int P, const int *__
             while (b >= 0 && pobs[o0 + b] > v) { pobs[o0 + b + 1] = pobs[o0 + b]; --b; }
             pobs[o0 + b + 1] = v;
         }
+}
+
+// pcam[e] = camera of list entry e, bcam[b] = (lowest, highest) camera in the lists of landmarks 64 b .. 64 b + 63 (a
+// wavefront each); meta->unsorted is set when the cameras of some list do not ascend.
+__global__ __launch_bounds__(256) void ba_list_cams_kernel(int P, const int *__restrict__ pptr, const int *__restrict__ pobs,
+                                                           const int *__restrict__ cam32, int *__restrict__ pcam,
+                                                           int2 *__restrict__ bcam, BaMeta *__restrict__ meta)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int prev = -1, lo = 0x7fffffff, hi = -1;
+    bool bad = false;
+    if (p < P)
+        for (int e = pptr[p]; e < pptr[p + 1]; ++e) {
+            const int c = cam32[pobs[e]];
+            pcam[e] = c;
+            bad = bad || c < prev;
+            prev = c;
+            lo = min(lo, c);
+            hi = max(hi, c);
+        }
+    if (bad) meta->unsorted = 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d));
+        hi = max(hi, __shfl_xor(hi, d));
+    }
+    if ((threadIdx.x & 63) == 0 && p - (p & 63) <= P) bcam[p >> 6] = int2{lo, hi};
 }
 
 __global__ __launch_bounds__(256) void ba_widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n)
@@ -2429,6 +2652,8 @@ extern "C" int vo_ba_create_filtered(vo_ctx *ctx, int F, int P, int O, const int
         hipLaunchKernelGGL(ba_lists_fill_kernel, dim3(ob), dim3(256), 0, ctx->stream, (const int64_t *)ba->pi, (const BaMeta *)d_meta,
                            (const int *)ba->pptr, (const int *)d_slot, ba->pobs);
         hipLaunchKernelGGL(ba_lists_sort_kernel, dim3((P + 3) / 4), dim3(256), 0, ctx->stream, P, (const int *)ba->pptr, ba->pobs);
+        hipLaunchKernelGGL(ba_list_cams_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, P, (const int *)ba->pptr,
+                           (const int *)ba->pobs, (const int *)ba->cam32, ba->pcam, ba->bcam, d_meta);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { vo_set_error("vo_ba_create_filtered: launch failed: %s", hipGetErrorString(e)); return fail(VO_EHIP); }
@@ -2441,6 +2666,7 @@ extern "C" int vo_ba_create_filtered(vo_ctx *ctx, int F, int P, int O, const int
     ba->O = O ? meta.kept : 0;
     ba->obs_start = O ? meta.frozen : 0;
     ba->cam_first = (O && meta.kept > meta.frozen) ? meta.cam_first : F;
+    ba->lists_sorted = !meta.unsorted;
     ba_configure(ba);
     *n_kept = ba->O;
     *obs_start = ba->obs_start;
@@ -2490,6 +2716,15 @@ static int ba_try_step_enqueue(vo_ba *ba, double lambda, const BaCtl *ctl)
         // lane every two cycles), so fewer workgroups are slower in proportion, whatever their flush saves
         const int want = (256 + strips - 1) / strips;
         if (slices > want) slices = want;
+        if (ba->pairs) {
+            hipLaunchKernelGGL(ba_point_inverse_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->Hpp[c], lambda,
+                               ba->Dpinv, ctl);
+            int pslices = (ba->P + 63) / 64;                                   // a workgroup takes 64 landmarks at a time
+            if (pslices > want) pslices = want;
+            hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(pslices, strips), dim3(SCHUR_THREADS), ba->strip_lds + 8 * (size_t)n,
+                               ctx->stream, n, ba->P, ba->F, ba->cam_first, ba->strip_budget, ba->pptr, ba->pobs, ba->pcam, (const int2 *)ba->bcam, ba->Hcp[c],
+                               ba->g[c], (const double *)ba->Dpinv, ba->S, ba->rhs, ctl);
+        } else
         hipLaunchKernelGGL(ba_schur_strip_kernel, dim3(slices, strips), dim3(SCHUR_THREADS), ba->strip_lds, ctx->stream, n, ba->P,
                            ba->F, ba->cam_first, ba->strip_budget, ba->pptr, ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], lambda, ba->Dpinv,
                            ba->S, ba->rhs, ctl);

@@ -148,6 +148,38 @@ def ba_problem(F=10, P=5000, K=K_KITTI, visibility=1.0, seed=0, obs_noise=0.5):
                 F=F, P=P)
 
 
+def ba_window_problem(F=107, births_every=7, per_birth=1600, survive=0.86, K=K_KITTI, seed=0, obs_noise=0.4):
+    """Seeded BA window shaped like the frame loop's: `per_birth` landmarks start at every `births_every`-th camera
+    (a re-bootstrap) and each is seen by consecutive cameras from there on, surviving a frame with probability
+    `survive` -- runs of neighbouring cameras, a few observations for most landmarks and dozens for some, where
+    ba_problem spreads a landmark's observations over random cameras.  Landmarks are numbered in order of first
+    appearance and the observations are sorted by camera, then landmark.  Same dict as ba_problem."""
+    rng = np.random.default_rng(seed)
+    Kd = K.astype(np.float64)
+    cams = np.zeros((F, 6))
+    cams[:, :3] = rng.normal(0, 0.01, (F, 3))
+    cams[:, 5] = -0.5 * np.arange(F)
+    births = np.repeat(np.arange(0, F, births_every), per_birth)
+    P = births.size
+    life = rng.geometric(1.0 - survive, P)                      # cameras that see the landmark, birth included
+    last = np.minimum(births + life, F)                          # exclusive
+    pts = rng.uniform([-20, -3, 6], [20, 3, 60], (P, 3))
+    pts[:, 2] += 0.5 * births                                   # in front of the camera that first sees it
+    ci, pi, obs = [], [], []
+    for f in range(F):
+        idx = np.nonzero((births <= f) & (f < last))[0]
+        Xc = pts[idx] @ rodrigues(cams[f, :3]).T + cams[f, 3:]
+        ok = Xc[:, 2] > 1.0
+        idx, Xc = idx[ok], Xc[ok]
+        uv = Xc @ Kd.T
+        uv = uv[:, :2] / uv[:, 2:]
+        ci.append(np.full(idx.size, f, np.int64)); pi.append(idx.astype(np.int64))
+        obs.append(uv + rng.normal(0, obs_noise, (idx.size, 2)))
+    x = np.hstack([(cams + rng.normal(0, 1e-3, cams.shape)).ravel(), (pts + rng.normal(0, 0.05, pts.shape)).ravel()])
+    return dict(x=x, ci=np.concatenate(ci), pi=np.concatenate(pi), obs=np.concatenate(obs).astype(np.float32), K=Kd,
+                F=F, P=P)
+
+
 def sift_like_descriptors(n1=3000, n2=3000, shared=0.6, jitter=6.0, seed=5):
     """Two sets of 128-entry descriptors shaped like SIFT's: non-negative, normalised to length 512,
     entries clipped and rounded to bytes, stored as float32.  The first `shared * min(n1, n2)` rows of
