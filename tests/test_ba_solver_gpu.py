@@ -154,8 +154,9 @@ def test_device_inputs_and_unseen_landmarks(oracle, ctx):
 
 
 def test_parameter_vector_beyond_the_page_locked_paths(ctx):
-    """A parameter vector of more than 1 MiB (the bound of the context's page-locked ring and result area) takes the
-    fallback copies in vo_ba_linearize / vo_ba_params: the same cost as the residual call, the vector back unchanged."""
+    """A parameter vector of more than 1 MiB (one piece of the context's page-locked ring, and the bound of its result
+    area) goes up in several pieces and comes back through the runtime's copy in vo_ba_linearize / vo_ba_params: the
+    same cost as the residual call, the vector back unchanged."""
     from visual_odometry_amd import hip
     pb = synth.ba_problem(F=4, P=400, visibility=1.0, seed=4)
     F, K = pb["F"], pb["K"]

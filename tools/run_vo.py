@@ -193,7 +193,9 @@ def main():
                       "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
                       **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()},
                           "total_ms_of_parts": {k: float(np.sum(v) * 1e3) for k, v in parts.items()},
-                          "calls_of_parts": {k: len(v) for k, v in parts.items()}, "ba_windows": windows} if parts else {})}))
+                          "calls_of_parts": {k: len(v) for k, v in parts.items()}, "ba_windows": windows,
+                          "ba_ms_per_window": {k: [round(t * 1e3, 3) for t in parts.get(k, [])]
+                                               for k in ("BaSolver.filtered", "BaSolver.solve", "_ba_window")}} if parts else {})}))
 
 
 if __name__ == "__main__":
