@@ -2096,6 +2096,17 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_backsolve_kernel(int n, int
     for (int i = tid; i < n; i += SOLVEB_THREADS) dc[i] = dead_cam[i / 6] ? 0.0 : bs[i];
 }
 
+// Lanes per landmark in the two kernels below that walk a landmark's observation list: with a lane per landmark a
+// wavefront lasts as long as its longest list (sixty observations where most have six), every step a dependent read.
+#define BA_LIST_LANES 8
+// Sum over the BA_LIST_LANES neighbouring lanes of a landmark; every one of them gets the total.
+__device__ __forceinline__ double list_lanes_sum(double v)
+{
+#pragma unroll
+    for (int d = 1; d < BA_LIST_LANES; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
 // dp = Dp^-1 (-g_p - sum_obs Hcp^T dc[camera]); candidate = current + (dc, dp).
 __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, const int *__restrict__ pptr,
                                                          const int *__restrict__ pobs, const int *__restrict__ cam,
@@ -2105,16 +2116,13 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, co
                                                          double *__restrict__ x_new, const BaCtl *__restrict__ ctl = nullptr)
 {
     if (ctl && ctl->done) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < n) x_new[p] = x[p] + dc[p];
-    if (p >= P) return;
-    double sabs = 0;
-    for (int k = 0; k < 9; ++k) sabs += fabs(Hpp[9 * (int64_t)p + k]);
-    const int64_t at = 6 * (int64_t)F + 3 * (int64_t)p;
-    double d[3] = {0, 0, 0};
-    if (sabs != 0) {
-        double bk[3] = {-g[at], -g[at + 1], -g[at + 2]};
-        for (int o = pptr[p]; o < pptr[p + 1]; ++o) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) x_new[t] = x[t] + dc[t];
+    const int p = t / BA_LIST_LANES, sub = t % BA_LIST_LANES;
+    const bool live = p < P;                           // the lanes of a landmark are all live or all not
+    double bk[3] = {0, 0, 0};
+    if (live)
+        for (int o = pptr[p] + sub; o < pptr[p + 1]; o += BA_LIST_LANES) {
             const int ob = pobs[o];
             const double *h = Hcp + 18 * (int64_t)ob, *q = dc + 6 * cam[ob];
             for (int a = 0; a < 6; ++a) {
@@ -2123,32 +2131,48 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n, int P, int F, co
                 bk[2] -= h[3 * a + 2] * q[a];
             }
         }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) bk[a] = list_lanes_sum(bk[a]);
+    if (!live || sub != 0) return;
+    double sabs = 0;
+    for (int k = 0; k < 9; ++k) sabs += fabs(Hpp[9 * (int64_t)p + k]);
+    const int64_t at = 6 * (int64_t)F + 3 * (int64_t)p;
+    double d[3] = {0, 0, 0};
+    if (sabs != 0) {
+        for (int a = 0; a < 3; ++a) bk[a] -= g[at + a];
         const double *iv = Dpinv + 9 * (int64_t)p;
         for (int a = 0; a < 3; ++a) d[a] = iv[3 * a] * bk[0] + iv[3 * a + 1] * bk[1] + iv[3 * a + 2] * bk[2];
     }
     for (int a = 0; a < 3; ++a) x_new[at + a] = x[at + a] + d[a];
 }
 
-// Hpp[p] = sum Jp^T Jp, g_p = sum Jp^T r over the observations of landmark p (one lane per
-// landmark; observations without Jacobian rows carry Jp = 0).
+// Hpp[p] = sum Jp^T Jp, g_p = sum Jp^T r over the observations of landmark p (BA_LIST_LANES lanes per
+// landmark, each taking every BA_LIST_LANES-th entry of the list; observations without Jacobian rows carry Jp = 0).
 __global__ __launch_bounds__(256) void ba_point_gather_kernel(int P, int F, const int *__restrict__ pptr,
                                                               const int *__restrict__ pobs, const double *__restrict__ Jp,
                                                               const double *__restrict__ r, double *__restrict__ Hpp,
                                                               double *__restrict__ g, const BaCtl *__restrict__ ctl = nullptr)
 {
     if (ctl && ctl->done) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t / BA_LIST_LANES, sub = t % BA_LIST_LANES;
+    const bool live = p < P;
     double h[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
-    for (int o = pptr[p]; o < pptr[p + 1]; ++o) {
-        const int64_t i = pobs[o];
-        const double *j = Jp + 6 * i;
-        const double j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3], j4 = j[4], j5 = j[5];
-        const double r0 = r[2 * i], r1 = r[2 * i + 1];
-        h[0] += j0 * j0 + j3 * j3; h[1] += j0 * j1 + j3 * j4; h[2] += j0 * j2 + j3 * j5;
-        h[3] += j1 * j1 + j4 * j4; h[4] += j1 * j2 + j4 * j5; h[5] += j2 * j2 + j5 * j5;
-        gp[0] += j0 * r0 + j3 * r1; gp[1] += j1 * r0 + j4 * r1; gp[2] += j2 * r0 + j5 * r1;
-    }
+    if (live)
+        for (int o = pptr[p] + sub; o < pptr[p + 1]; o += BA_LIST_LANES) {
+            const int64_t i = pobs[o];
+            const double *j = Jp + 6 * i;
+            const double j0 = j[0], j1 = j[1], j2 = j[2], j3 = j[3], j4 = j[4], j5 = j[5];
+            const double r0 = r[2 * i], r1 = r[2 * i + 1];
+            h[0] += j0 * j0 + j3 * j3; h[1] += j0 * j1 + j3 * j4; h[2] += j0 * j2 + j3 * j5;
+            h[3] += j1 * j1 + j4 * j4; h[4] += j1 * j2 + j4 * j5; h[5] += j2 * j2 + j5 * j5;
+            gp[0] += j0 * r0 + j3 * r1; gp[1] += j1 * r0 + j4 * r1; gp[2] += j2 * r0 + j5 * r1;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) h[a] = list_lanes_sum(h[a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gp[a] = list_lanes_sum(gp[a]);
+    if (!live || sub != 0) return;
     double *hp = Hpp + 9 * (int64_t)p;
     hp[0] = h[0]; hp[1] = h[1]; hp[2] = h[2];
     hp[3] = h[1]; hp[4] = h[3]; hp[5] = h[4];
@@ -2176,7 +2200,7 @@ static int ba_linearize_into(vo_ba *ba, int slot, const BaCtl *ctl = nullptr)
     hipLaunchKernelGGL(ba_cam_sum_kernel, dim3((ba->F * 42 + 255) / 256), dim3(256), 0, ctx->stream, ba->F, ba->cam_rep,
                        ba->Hcc[slot], ba->g[slot], 0, (double *)nullptr, (const double *)(ba->cam_rep + cam_doubles), ba->cost[slot], ctl);
     VO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(ba_point_gather_kernel, dim3((ba->P + 255) / 256), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
+    hipLaunchKernelGGL(ba_point_gather_kernel, dim3((unsigned)(((size_t)ba->P * BA_LIST_LANES + 255) / 256)), dim3(256), 0, ctx->stream, ba->P, ba->F, ba->pptr,
                        ba->pobs, ba->Jp, ba->r, ba->Hpp[slot], ba->g[slot], ctl);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
@@ -2762,8 +2786,8 @@ static int ba_try_step_enqueue(vo_ba *ba, double lambda, const BaCtl *ctl)
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
                            ba->Hcc[c], ba->g[c], lambda, ba->dc, ba->flag, ctl);
     VO_HIP_CHECK(hipGetLastError());
-    const int work = ba->P > n ? ba->P : n;
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3((work + 255) / 256), dim3(256), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
+    const size_t work = (size_t)ba->P * BA_LIST_LANES > (size_t)n ? (size_t)ba->P * BA_LIST_LANES : (size_t)n;
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, ctx->stream, n, ba->P, ba->F, ba->pptr,
                        ba->pobs, ba->cam32, ba->Hpp[c], ba->Hcp[c], ba->g[c], ba->Dpinv, ba->dc, ba->x[c], ba->x[o], ctl);
     VO_HIP_CHECK(hipGetLastError());
     return ba_linearize_into(ba, o, ctl);
@@ -2861,15 +2885,16 @@ extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_ite
     const size_t n16 = ba->slot_bytes / 16;
     unsigned copy_blocks = (unsigned)((n16 + 255) / 256);
     if (copy_blocks > 4096) copy_blocks = 4096;
-    // Trial steps are queued several at a time and the record read back once per round: a window needs 5-8 of them,
-    // and a surplus step behind the one that ended the loop costs its launches only (every kernel leaves on `done`).
+    // Trial steps are queued several at a time and the record read back once per round: a window of the frame loop
+    // needs four to six of them, five most often.  A surplus step behind the one that ended the loop costs its
+    // launches only (every kernel leaves on `done`), but at 30-40 launches that is 80 us.
     const int cap = ba->O == 0 ? 0 : 10 * (max_iters > 0 ? max_iters : 1);
     if (cap == 0) {
         VO_RESULT(ctx, &h, ba->ctl, sizeof(BaCtl));
         VO_RESULTS_FINISH(ctx);
     }
     for (int queued = 0, round = 0; queued < cap; ++round) {
-        int batch = round == 0 ? 6 : 4;
+        int batch = round == 0 ? 5 : 3;
         if (batch > cap - queued) batch = cap - queued;
         for (int k = 0; k < batch; ++k) {
             if ((rc = ba_try_step_enqueue(ba, 0.0, ba->ctl))) return rc;
