@@ -2014,6 +2014,7 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_solve_blocked_kernel(int n,
 // W rows of L^T at a time from the bottom: the rows come in with coalesced reads, the W x W triangle is solved by one
 // wave in registers, the rest of the vector is updated in one pass.  One workgroup.  dc = x, zero for cameras
 // without unknowns and when flag[0] says the factorisation failed.
+template <int PF>
 __global__ __launch_bounds__(SOLVEB_THREADS) void ba_backsolve_kernel(int n, int F, int first, int W, const double *__restrict__ A,
                                                                       const double *__restrict__ b, const double *__restrict__ dinv_g,
                                                                       const double *__restrict__ Hcc, double *__restrict__ dc,
@@ -2042,7 +2043,10 @@ __global__ __launch_bounds__(SOLVEB_THREADS) void ba_backsolve_kernel(int n, int
     // every 32nd entry.  They do not depend on the unknowns, so the next block's are read into registers while the
     // current block is solved: a block then costs its barriers and arithmetic, not a trip to memory.
     static_assert(SOLVEB_MAX_W * 32 <= SOLVEB_THREADS, "a row of the block per 32 threads");
-    constexpr int PF = 1536 / 32;
+    // PF: entries of a row a thread may hold, 32 PF >= n - first (the host picks the smallest of 8, 16, 24, 48: the
+    // loops below are unrolled PF times with a test each, which at 48 was a third of a block's time).  A variant with an
+    // unknown per thread (no LDS staging, one barrier per block, four blocks in flight) that read whole rows took twice
+    // as long, and warming the L2 with the factor from other workgroups changed nothing.
     const int pr = tid >> 5, px = tid & 31;
     double pf[PF];
     auto fetch = [&](int kf) {
@@ -2317,8 +2321,10 @@ static void ba_configure(vo_ba *ba)
         const size_t lds = ((size_t)w * (n + 1) + 2 * (size_t)n) * 8;
         if (w >= 4 && hipFuncSetAttribute((const void *)ba_solve_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds) == hipSuccess &&
-            hipFuncSetAttribute((const void *)ba_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
-                hipSuccess) {
+            hipFuncSetAttribute((const void *)ba_backsolve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+            hipFuncSetAttribute((const void *)ba_backsolve_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+            hipFuncSetAttribute((const void *)ba_backsolve_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+            hipFuncSetAttribute((const void *)ba_backsolve_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
             ba->solve_w = (int)w;
             ba->solve_lds = lds;
         }
@@ -2718,6 +2724,21 @@ extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem,
     return VO_OK;
 }
 
+// ba_backsolve_kernel with the smallest per-thread row buffer that covers the columns with unknowns.
+static void ba_backsolve_launch(vo_ba *ba, int first, const double *A, const double *b, const double *dinv, const double *Hcc,
+                                const BaCtl *ctl)
+{
+    vo_ctx *ctx = ba->ctx;
+    const int n = ba->n, need = (n - first + 31) / 32;
+#define BA_BACKSOLVE(PF) hipLaunchKernelGGL(ba_backsolve_kernel<PF>, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, \
+                                            first, ba->solve_w, A, b, dinv, Hcc, ba->dc, (const int *)ba->flag, ctl)
+    if (need <= 8) BA_BACKSOLVE(8);
+    else if (need <= 16) BA_BACKSOLVE(16);
+    else if (need <= 24) BA_BACKSOLVE(24);
+    else BA_BACKSOLVE(48);
+#undef BA_BACKSOLVE
+}
+
 // One trial step queued on the context's stream: candidate = current + LM step for the damping `lambda` (or, with
 // ctl, the damping the device-side record holds; every kernel then leaves at once when the record says done),
 // linearised into the other slot.
@@ -2772,15 +2793,11 @@ static int ba_try_step_enqueue(vo_ba *ba, double lambda, const BaCtl *ctl)
             hipLaunchKernelGGL(ba_solve_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S, ba->rhs,
                                ba->Lf, ba->zf, ba->dinv, ba->flag, ctl);
         }
-        hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F, first,
-                           ba->solve_w, (const double *)ba->Lf, (const double *)ba->zf, (const double *)ba->dinv, ba->Hcc[c], ba->dc,
-                           (const int *)ba->flag, ctl);
+        ba_backsolve_launch(ba, first, ba->Lf, ba->zf, ba->dinv, ba->Hcc[c], ctl);
     } else if (ba->solve_w) {
         hipLaunchKernelGGL(ba_solve_blocked_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
                            6 * ba->cam_first, ba->solve_w, ba->S, ba->rhs, ba->Hcc[c], ba->g[c], lambda, ba->flag, ba->dinv, ctl);
-        hipLaunchKernelGGL(ba_backsolve_kernel, dim3(1), dim3(SOLVEB_THREADS), ba->solve_lds, ctx->stream, n, ba->F,
-                           6 * ba->cam_first, ba->solve_w, (const double *)ba->S, (const double *)ba->rhs, (const double *)ba->dinv,
-                           ba->Hcc[c], ba->dc, (const int *)ba->flag, ctl);
+        ba_backsolve_launch(ba, 6 * ba->cam_first, ba->S, ba->rhs, ba->dinv, ba->Hcc[c], ctl);
     }
     else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), 0, ctx->stream, n, ba->F, ba->S, ba->rhs,
