@@ -1728,8 +1728,9 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
                                                             int *__restrict__ flag, const BaCtl *__restrict__ ctl = nullptr)
 {
     __shared__ double tile[PANEL_MAX_W * 64];
-    if (ctl && ctl->done) return;
-    if (flag[0] == 0) return;
+    // whether there is anything to do is looked at after the panel's reads have been issued: tested first, the two
+    // flags are a trip to memory of their own before every launch's real reads (20 launches a trial step)
+    const int stop = (ctl ? ctl->done : 0) | (flag[0] == 0);
     const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     const int t0 = k0 + w, m = n - t0;          // trailing rows 0 .. m (row m: the right-hand side), columns 0 .. m-1
     int bi, bj;
@@ -1755,6 +1756,7 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
     }
     double cur[2][2][4];
     solveb_read_block(A, b, n, t0, bi, bj, l4, l15, cur);
+    if (stop) return;
     // Entry c of every row -- the triangle's (tv, a row per lane) and this block's (v) -- follows from the row's
     // earlier entries and row c of the triangle: x_c -= sum_q (x_q / d_q) T[c][q].  T[c][q] is final after step q
     // and comes by a lane read that serves both; the columns stay unscaled (c_ik = L_ik d_k).
