@@ -14,7 +14,7 @@ _, klt_bytes = bench.algorithmic_bytes(bench.MAX_LEVEL, n_kp)
 hbm = k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024
 xcd_cycles = k["GRBM_GUI_ACTIVE"] / 8
 out = {
-    "kernel": "klt_track3_kernel", "frames_per_launch": frames, "round": 2, "command": command,
+    "kernel": "klt_track3_kernel", "frames_per_launch": frames, "round": 3, "command": command,
     "FETCH_SIZE_KB_per_launch": k["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": k["WRITE_SIZE"],
     "TCC_MISS_per_launch": k["TCC_MISS_sum"], "TCC_REQ_per_launch": k["TCC_REQ_sum"],
     "hbm_bytes_per_launch": int(round(hbm)), "algorithmic_bytes_per_launch": int(klt_bytes * frames),
