@@ -19,6 +19,8 @@ iterations) and the refit -- through vo_track_pnp_batch: frames/s with a pose pe
 landmarks project onto the true positions of its keypoints in the next frame under a seeded pose, 10 % of them
 displaced (outliers).  A group begins its step's chain, and waits for the chain of its previous step only when it
 comes round again: one synchronisation per step and group, the other groups' chains running meanwhile.
+The default single-GPU line carries that figure as `frame_mode`: a child process runs `--mode frame` for 300 steps
+before this process touches the GPU (`--no-frame-line`, or `--no-cpu-baseline` as profiling runs pass it, leave it out).
 
 A GPU's streams are dealt to `--groups` launch groups (default 2).  Each group owns a
 tracker HIP stream and a pyramid HIP stream and issues one tracker launch per step, so
@@ -216,6 +218,22 @@ def cpu_baseline(frames, pts, max_level=MAX_LEVEL, budget_s=10.0, cores=0, frame
     return res
 
 
+def frame_mode_figure(steps=300):
+    """The tracked frame with a pose (`--mode frame`) measured by a child process of this script, for the default
+    line's `frame_mode` field.  Called before this process touches torch or the GPU: the child has the device to
+    itself and has exited when the headline measurement starts."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "frame", "--steps", str(steps), "--warmup", "20", "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        rec = json.loads(line)
+        return {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"], "ms_per_step": rec["ms_per_step"],
+                "streams_per_gpu": rec["config"]["streams_per_gpu"], "pose_check": rec["config"].get("pose_check"),
+                "command": "python bench.py --mode frame --steps %d --warmup 20 --no-cpu-baseline" % steps}
+    except Exception as e:      # the headline line does not depend on it
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched multi-GPU run: start one fresh process per rank, wait, and pass
     on the first failure.  This process never initialises a GPU and replaces no running program."""
@@ -275,6 +293,8 @@ def parse_args(argv):
                     help="requested last pyramid level (default 3 = the headline 4-level configuration; the reference "
                          "asks for 8, which the level-size rule clamps to 4 on 1241x376 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-line", action="store_true",
+                    help="leave out the `frame_mode` field of the default line (a `--mode frame` run in a child process first)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the all-cores CPU column (0 = the CPU share)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="build each frame's pyramid on the tracker's stream, right before it is tracked")
@@ -336,6 +356,9 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run:
         sys.exit(dry_run(args, rank, world))
+    frame_extra = None
+    if args.mode == "klt" and world == 1 and not args.no_cpu_baseline and not args.no_frame_line:
+        frame_extra = frame_mode_figure()
 
     import torch
     import torch.distributed as dist
@@ -628,6 +651,8 @@ def main(argv=None):
             res["config"]["synchronisations_per_step"] = G
             res["config"]["batches_in_flight_per_group"] = max(1, args.depth)
             res["config"]["pose_check"] = pose_check
+        if frame_extra is not None:
+            res["frame_mode"] = frame_extra        # the same streams with a pose per frame, measured by `--mode frame`
         if elapsed * 1e3 < 50.0:
             res["short_timed_region"] = True       # steps x ms_per_step < 50 ms: one scheduler hiccup away from noise
         if world == 1 and not args.no_cpu_baseline:
