@@ -267,6 +267,17 @@ int vo_cheirality_vote(vo_ctx *ctx, const float *pts1, const float *pts2, int n,
 typedef struct vo_ba vo_ba;
 int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int64_t *pi, const double *obs,
                  const double *K, int obs_start, int mem, vo_ba **out);
+/* vo_ba_window_assemble (host-side, no GPU work): the observation arrays of a bundle-adjustment window from the
+ * per-frame keypoint / trajectory lists, i.e. the loop of ContinuousVO._bundle_adjustment that fills camera_indices,
+ * point_indices and keypoints and numbers the window's landmarks in order of first appearance
+ * (vo_pipeline/continuousVO.py:286-306), in one pass.  Frame f of the F window frames has counts[f] observations:
+ * keypoints kps[f] (counts[f] x 2 float32) of trajectories ids[f] (counts[f] int32, non-negative).  Fills ci
+ * (frame of every observation, ascending), pi (landmark number of its trajectory), obs (the keypoints, concatenated)
+ * -- O = sum(counts) entries each -- and traj_of_point (the trajectory of landmark 0, 1, ...; room for O entries),
+ * *n_points = landmarks in the window.  Returns 1, with nothing written, when the ids are too sparse for a table (their
+ * span exceeds 8 O + 1024: the caller numbers them by sorting instead); VO_EINVAL for a negative id. */
+int vo_ba_window_assemble(int F, const int32_t *counts, const float *const *kps, const int32_t *const *ids, int64_t *ci,
+                          int64_t *pi, float *obs, int32_t *traj_of_point, int32_t *n_points);
 /* vo_ba_create_filtered: vo_ba_create preceded by the outlier pre-filter of BundleAdjustment._preprocess_data
  * (vo_pipeline/bundleAdjustment.py:111-134) on the device: obs is (O,2) float64, or float32 when obs_f32 is set (the
  * pipeline's keypoints, widened on the device exactly as the host conversion would); the residual is evaluated at x0

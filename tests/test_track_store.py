@@ -130,3 +130,38 @@ def test_window_indices():
     np.testing.assert_array_equal(order, [5, 6, 9])
     ci, pi, order = continuousVO.window_indices([np.array([], int)])
     assert ci.size == pi.size == order.size == 0
+
+
+def test_window_assembler_equals_window_indices():
+    """The library's one-pass host helper (vo_ba_window_assemble) against the numpy numbering: loop-shaped id lists
+    (runs that thin out, new ids at intervals), repeated ids inside a frame, empty frames, an empty window; ids too
+    sparse for its table hand back to the caller, negative ids are refused."""
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(11)
+    alive, nxt, ids, kps = np.zeros(0, np.int32), 7, [], []
+    for f in range(23):
+        alive = alive[rng.random(alive.size) > 0.15]
+        if f % 4 == 0:
+            alive = np.concatenate([alive, np.arange(nxt, nxt + 40, dtype=np.int32)])
+            nxt += 40 + int(rng.integers(0, 5))
+        frame = alive.copy() if f != 9 else np.zeros(0, np.int32)
+        if f == 5:
+            frame = np.concatenate([frame[::-1], frame[:3]])          # no order inside a frame, ids seen twice
+        ids.append(frame)
+        kps.append(rng.normal(size=(frame.size, 2)).astype(np.float32))
+    ci, pi, obs, order = hip.ba_window_assemble(kps, ids)
+    want_ci, want_pi, want_order = continuousVO.window_indices(ids)
+    np.testing.assert_array_equal(ci, want_ci)
+    np.testing.assert_array_equal(pi, want_pi)
+    np.testing.assert_array_equal(order, want_order)
+    np.testing.assert_array_equal(obs, np.concatenate(kps))
+    assert ci.dtype == np.int64 and pi.dtype == np.int64 and obs.dtype == np.float32
+    ci, pi, obs, order = hip.ba_window_assemble([np.zeros((0, 2), np.float32)], [np.zeros(0, np.int32)])
+    assert ci.size == pi.size == order.size == 0 and obs.shape == (0, 2)
+    ci, pi, obs, order = hip.ba_window_assemble([], [])
+    assert ci.size == 0
+    assert hip.ba_window_assemble([np.zeros((2, 2), np.float32)], [np.array([0, 10 ** 6], np.int32)]) is None
+    with pytest.raises(ValueError):
+        hip.ba_window_assemble([np.zeros((2, 2), np.float32)], [np.array([3, -1], np.int32)])
+    with pytest.raises(ValueError):
+        hip.ba_window_assemble([np.zeros((3, 2), np.float32)], [np.array([3, 4], np.int32)])

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vo_ba_create_filtered": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_f64p, c_vp,
                                              ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp),
                                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "vo_ba_window_assemble": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int32)]),
     "vo_ba_destroy": (None, [c_vp]),
     "vo_ba_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_vp, ctypes.c_int,
                                    c_vp]),

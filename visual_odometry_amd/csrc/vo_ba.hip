@@ -2465,6 +2465,51 @@ extern "C" int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci,
     return rc;
 }
 
+// ---- a window's observation arrays from the per-frame lists (host) ----------------------------------------------
+extern "C" int vo_ba_window_assemble(int F, const int32_t *counts, const float *const *kps, const int32_t *const *ids, int64_t *ci,
+                                     int64_t *pi, float *obs, int32_t *traj_of_point, int32_t *n_points)
+{
+    VO_REQUIRE(F >= 0 && n_points && (F == 0 || (counts && kps && ids)), "vo_ba_window_assemble: NULL argument or F=%d", F);
+    *n_points = 0;
+    int64_t O = 0;
+    int32_t lo = INT32_MAX, hi = -1;
+    for (int f = 0; f < F; ++f) {
+        VO_REQUIRE(counts[f] >= 0 && (counts[f] == 0 || (kps[f] && ids[f])), "vo_ba_window_assemble: frame %d: bad count or NULL list", f);
+        for (int k = 0; k < counts[f]; ++k) {
+            const int32_t t = ids[f][k];
+            lo = t < lo ? t : lo;
+            hi = t > hi ? t : hi;
+        }
+        O += counts[f];
+    }
+    if (O == 0) return VO_OK;
+    VO_REQUIRE(ci && pi && obs && traj_of_point, "vo_ba_window_assemble: NULL output");
+    VO_REQUIRE(lo >= 0, "vo_ba_window_assemble: negative trajectory id %d", lo);
+    const int64_t span = (int64_t)hi - lo + 1;
+    if (span > 8 * O + 1024) return 1;                      // too sparse for a table: the caller sorts
+    int32_t *number = (int32_t *)malloc((size_t)span * 4);
+    if (!number) { vo_set_error("vo_ba_window_assemble: out of host memory"); return VO_ENOMEM; }
+    memset(number, 0xff, (size_t)span * 4);
+    int32_t P = 0;
+    int64_t at = 0;
+    for (int f = 0; f < F; ++f) {
+        const int32_t n = counts[f];
+        if (n) memcpy(obs + 2 * at, kps[f], (size_t)n * 8);
+        for (int k = 0; k < n; ++k, ++at) {
+            int32_t &slot = number[ids[f][k] - lo];
+            if (slot < 0) {
+                slot = P;
+                traj_of_point[P++] = ids[f][k];
+            }
+            ci[at] = f;
+            pi[at] = slot;
+        }
+    }
+    free(number);
+    *n_points = P;
+    return VO_OK;
+}
+
 // ---- a window's solver built from raw observations: outlier pre-filter, compaction and lists on the device ----
 // BundleAdjustment._preprocess_data (vo_pipeline/bundleAdjustment.py:111-134) evaluates the residual at the start,
 // drops the observations whose squared reprojection error exceeds a threshold, and hands the rest to the solver.  Done

@@ -952,6 +952,44 @@ class BaSolver:
             pass
 
 
+def ba_window_assemble(kps_per_frame, ids_per_frame):
+    """Host-side (vo_ba_window_assemble): the observation arrays of a bundle-adjustment window from per-frame lists of
+    keypoints ((n_f, 2) float32) and trajectory ids ((n_f,) int32) -> (camera_indices (O,) int64 ascending,
+    point_indices (O,) int64, keypoints (O, 2) float32, trajectory id of every window landmark in order of first
+    appearance (P,) int32), or None when the ids are too sparse for the library's table (the caller then numbers
+    them by sorting)."""
+    lib = _lib.load()
+    F = len(ids_per_frame)
+    if len(kps_per_frame) != F:
+        raise ValueError("ba_window_assemble: keypoint and id lists differ in length")
+    # a window has a hundred frames and this runs at every keyframe: arrays that already are what the library reads
+    # (the track store's are) are passed as they are, the others converted
+    f32, i32 = np.dtype(np.float32), np.dtype(np.int32)
+    kps, ids = list(kps_per_frame), list(ids_per_frame)
+    counts = np.empty(F, np.int32)
+    for f in range(F):
+        k, t = kps[f], ids[f]
+        if not (type(k) is np.ndarray and k.dtype is f32 and k.ndim == 2 and k.flags.c_contiguous):
+            k = kps[f] = np.ascontiguousarray(k, np.float32).reshape(-1, 2)
+        if not (type(t) is np.ndarray and t.dtype is i32 and t.ndim == 1 and t.flags.c_contiguous):
+            t = ids[f] = np.ascontiguousarray(t, np.int32).ravel()
+        if k.shape[0] != t.shape[0] or k.shape[1] != 2:
+            raise ValueError("ba_window_assemble: a frame's keypoints and ids differ in length")
+        counts[f] = t.shape[0]
+    O = int(counts.sum())
+    kp_ptrs = (ctypes.c_void_p * max(F, 1))(*[k.ctypes.data for k in kps])
+    id_ptrs = (ctypes.c_void_p * max(F, 1))(*[t.ctypes.data for t in ids])
+    ci, pi = np.empty(O, np.int64), np.empty(O, np.int64)
+    obs, traj = np.empty((O, 2), np.float32), np.empty(O, np.int32)
+    n_points = ctypes.c_int32()
+    rc = lib.vo_ba_window_assemble(F, _ptr(counts), ctypes.cast(kp_ptrs, ctypes.c_void_p), ctypes.cast(id_ptrs, ctypes.c_void_p),
+                                   _ptr(ci), _ptr(pi), _ptr(obs), _ptr(traj), ctypes.byref(n_points))
+    if rc == 1:
+        return None
+    check(rc, "vo_ba_window_assemble")
+    return ci, pi, obs, traj[:n_points.value]
+
+
 def ransac_draw_subsets(rng_state: int, count: int, model_points: int, n_subsets: int, m1=None, m2=None,
                         max_attempts: int = 10000) -> Tuple[np.ndarray, int]:
     """Host-side: n_subsets index sets drawn as OpenCV's RANSAC loop draws them -> (subsets (n_subsets, model_points)

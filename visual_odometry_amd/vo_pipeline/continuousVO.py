@@ -9,7 +9,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .. import params
+from .. import hip, params
 from ..utils.frameQueue import FrameQueue
 from ..utils.matrix import hom_inv
 from .bootstrap import BootstrapInitializer
@@ -283,10 +283,17 @@ class ContinuousVO:
             kp, traj, _ = store.at_frame(old_frame_idx, with_landmarks=False)
             kps.append(kp)
             trajs.append(traj)
-        ci, pi, traj_of_point = window_indices(trajs)
+        # indices, concatenated keypoints and the landmark numbering in one pass of the library's host-side helper; ids too
+        # sparse for its table (not what this pipeline produces) are numbered by window_indices
+        done = hip.ba_window_assemble(kps, trajs)
+        if done is not None:
+            ci, pi, keypoints, traj_of_point = done
+        else:
+            ci, pi, traj_of_point = window_indices(trajs)
+            keypoints = np.concatenate(kps).astype(np.float32).reshape(-1, 2)
         landmark_ids = store.traj2landmark.lookup(traj_of_point)
         return (look_back, np.asarray(poses, dtype=np.float32), store.landmarks.array[landmark_ids].astype(np.float32),
-                ci, pi, np.concatenate(kps).astype(np.float32).reshape(-1, 2), landmark_ids)
+                ci, pi, keypoints, landmark_ids)
 
     def _bundle_adjustment(self, frame_idx: int, T: np.ndarray) -> np.ndarray:
         look_back, poses, landmarks, ci, pi, keypoints, landmark_ids = self._ba_window(frame_idx, T)
