@@ -95,13 +95,17 @@ def test_lm_step_matches_dense_numpy(oracle, ctx, F, P, vis, solve, monkeypatch)
 # observations ascend in camera), a landmark per wavefront ("strips"), sums straight into global memory ("global").
 # Windows shaped like the frame loop's (runs of neighbouring cameras, a few long tracks), a landmark seen twice by one
 # camera, and observations in no camera order (which the pair kernel does not take: the solver falls back by itself).
-@pytest.mark.parametrize("case", ["window", "window_wide", "twice", "shuffled"])
+@pytest.mark.parametrize("case", ["window", "window_wide", "twice", "shuffled", "small_no_lds"])
 @pytest.mark.parametrize("schur", ["", "strips", "global"])
 def test_schur_variants_match_dense_numpy(oracle, ctx, case, schur, monkeypatch):
     from visual_odometry_amd import hip
     if schur:
         monkeypatch.setenv("VO_BA_SCHUR", schur)
-    if case == "window_wide":
+    if case == "small_no_lds":
+        # a window that would live in LDS sent through the large-window kernels: one strip, a partial block of landmarks
+        monkeypatch.setenv("VO_BA_NO_LDS", "1")
+        pb = synth.ba_window_problem(F=9, births_every=3, per_birth=37, survive=0.9, seed=5)
+    elif case == "window_wide":
         pb = synth.ba_window_problem(F=90, births_every=6, per_birth=40, survive=0.93, seed=4)
     else:
         pb = synth.ba_window_problem(F=40, births_every=5, per_birth=50, survive=0.88, seed=3)
