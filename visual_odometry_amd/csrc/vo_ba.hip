@@ -671,6 +671,9 @@ __global__ __launch_bounds__(REFINE_THREADS) void refine_pose_kernel(const float
                                                                      const int *__restrict__ sel_dev, const int *__restrict__ n_dev,
                                                                      const int *__restrict__ mask_row, vo_batch_strides bs)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     // blockIdx.x: the problem (a stream of a batched frame), one workgroup each; its arrays start bs.work / bs.out /
     // bs.mask bytes after the problem before
     if (bs.count > 1) {

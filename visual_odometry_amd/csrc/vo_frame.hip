@@ -62,6 +62,9 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
                                                                 uint8_t *__restrict__ full, int *__restrict__ subsets,
                                                                 unsigned short *__restrict__ starts, vo_batch_strides bs)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ int wcount[2][FS_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
@@ -208,6 +211,9 @@ __global__ __launch_bounds__(64) void frame_bound_kernel(const int *__restrict__
                                                          int max_iters, double conf, vo_frame_meta *__restrict__ meta,
                                                          vo_batch_strides bs)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     const size_t b = blockIdx.x;
     counts = (const int *)((const char *)counts + b * bs.out);
     valid += b * bs.out;
@@ -234,6 +240,9 @@ __global__ __launch_bounds__(64 * FM_WAVES) void frame_mask_kernel(const int *__
                                                                    const uint64_t *__restrict__ states, size_t states_stride,
                                                                    vo_batch_strides bs)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (bs.count > 1) {
         const size_t b = blockIdx.y;

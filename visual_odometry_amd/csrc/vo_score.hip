@@ -24,6 +24,9 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
                                                               const int *__restrict__ n_dev, const int *__restrict__ first_dev,
                                                               vo_batch_strides bs, int hyp_lo, const int *__restrict__ skip_bound)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     // n_dev / first_dev (optional): the point count and the index of the first model live on the device, left there
     // by earlier kernels of the same stream (a negative first model: nothing to score).
     // blockIdx.z: the problem (a stream of a batched frame), whose arrays start bs.work / bs.out bytes after the

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__rest
                                                             double *__restrict__ Rt, uint8_t *__restrict__ valid,
                                                             vo_batch_strides bs, int samp_lo, const int *__restrict__ skip_bound)
 {
+    // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
+    // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
+    __builtin_amdgcn_s_setprio(3);
     const int s = samp_lo + blockIdx.x * SOLVER_THREADS + threadIdx.x;
     if (s >= S) return;
     {
