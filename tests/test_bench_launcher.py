@@ -87,3 +87,28 @@ def test_stream_cache_round_trip(tmp_path):
         assert np.abs(proj[:, :2] / proj[:, 2:] - moved[1, 0]).max() < 1e-2       # landmarks project onto the flow (float32 storage)
     finally:
         bench.H, bench.W, bench.N_KP = old
+
+
+def test_frame_mode_figure_never_breaks_the_headline(monkeypatch):
+    """The default line's `frame_mode` field comes from a child process; a child that fails or prints nothing usable
+    yields an `error` entry, a good one the figure with its command."""
+    import json as _json
+    import subprocess as _sp
+    import bench
+
+    class _Done:
+        def __init__(self, out):
+            self.stdout, self.stderr, self.returncode = out, "", 0
+
+    monkeypatch.setattr(_sp, "run", lambda *a, **k: _Done("warming up\n"))
+    assert "error" in bench.frame_mode_figure()
+
+    def boom(*a, **k):
+        raise _sp.TimeoutExpired(cmd="bench", timeout=1)
+    monkeypatch.setattr(_sp, "run", boom)
+    assert "TimeoutExpired" in bench.frame_mode_figure()["error"]
+    line = {"metric": "m", "value": 5.0, "unit": "frames/s", "steps": 300, "ms_per_step": 0.5,
+            "config": {"streams_per_gpu": 64, "pose_check": {"streams_with_pose": 64}}}
+    monkeypatch.setattr(_sp, "run", lambda *a, **k: _Done("noise\n" + _json.dumps(line) + "\n"))
+    got = bench.frame_mode_figure(steps=300)
+    assert got["value"] == 5.0 and got["pose_check"]["streams_with_pose"] == 64 and "--mode frame" in got["command"]
