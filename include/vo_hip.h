@@ -41,6 +41,9 @@ const char *vo_last_error(void);
 int vo_version(void);
 /* stream: a hipStream_t (may be NULL = the device's default stream). */
 int vo_ctx_create(int device, void *stream, vo_ctx **out);
+/* A context on a stream of its own (non-blocking: not ordered with the device's default stream), destroyed with it:
+ * for work that runs beside another context's, e.g. the two-view bootstrap beside a bundle-adjustment window. */
+int vo_ctx_create_own_stream(int device, vo_ctx **out);
 int vo_ctx_destroy(vo_ctx *ctx);
 int vo_sync(vo_ctx *ctx);
 /* Timing helpers (HIP events on the context's stream). */
@@ -306,6 +309,16 @@ typedef struct vo_ba_lm_stats {
 } vo_ba_lm_stats;
 int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
                 int stop_on_flat_reject, double *x_out, int mem, vo_ba_lm_stats *stats);
+/* The two halves of vo_ba_solve: _begin uploads x0, linearises and queues the first round of trial steps without
+ * waiting for anything; _finish reads the loop's record (queuing further rounds while the loop has not ended) and
+ * returns the result.  Between the two the caller is free to use other contexts -- ContinuousVO builds the next
+ * two-view bootstrap (vo_pipeline/continuousVO.py:223-236: the adjustment, then the bootstrap) on a second context
+ * while the window's trial steps run.  first_round: trial steps queued by _begin (0: five, what vo_ba_solve queues; a
+ * caller that overlaps other work asks for more, a surplus step costing only its empty launches).  One solve at a time
+ * per solver: a second _begin before _finish -> VO_ESTATE. */
+int vo_ba_solve_begin(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
+                      int stop_on_flat_reject, int first_round, int mem);
+int vo_ba_solve_finish(vo_ctx *ctx, vo_ba *ba, double *x_out, int mem, vo_ba_lm_stats *stats);
 int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem, double *cost);
 int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cost_new, int *solved);
 int vo_ba_accept(vo_ctx *ctx, vo_ba *ba);

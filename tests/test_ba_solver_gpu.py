@@ -383,3 +383,36 @@ def test_device_side_loop_empty_and_frozen_windows(ctx):
     x, st = s.solve(x0, max_iters=2)                                          # the iteration cap
     assert st["accepted"] <= 2
     s.close()
+
+
+def test_solve_in_two_halves_and_its_state_errors(ctx):
+    """vo_ba_solve_begin / _finish: the same result as the one call (to the order of the solver's float64 atomics), other
+    contexts usable in between, a longer first round changing nothing but the queue; a second begin before finish and a
+    finish without begin are state errors."""
+    from visual_odometry_amd import hip
+    from visual_odometry_amd._lib import VoError
+    pb = synth.ba_window_problem(F=30, births_every=5, per_birth=60, survive=0.9, seed=8)
+    F, P, K = pb["F"], pb["P"], pb["K"]
+    ci, pi, obs, x0 = pb["ci"], pb["pi"], pb["obs"].astype(np.float64), pb["x"]
+    start = _start(F, ci)
+    s = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+    want, want_stats = s.solve(x0)
+    s.close()
+    side = hip.Context.on_own_stream(0)
+    for first_round in (0, 2, 9):
+        s = hip.BaSolver(ctx, F, P, ci, pi, obs, K, start)
+        with pytest.raises(VoError):
+            s.solve_finish()
+        s.solve_begin(x0, first_round=first_round)
+        with pytest.raises(VoError):
+            s.solve_begin(x0)
+        # another context does unrelated work on its own stream meanwhile
+        r, cost = hip.ba_residual(side, x0, F, P, ci, pi, obs, K)
+        assert np.isfinite(cost) and r.shape == (2 * ci.size,)
+        got, stats = s.solve_finish()
+        assert stats["trial_steps"] == want_stats["trial_steps"] and stats["accepted"] == want_stats["accepted"]
+        assert stats["stop_reason"] == want_stats["stop_reason"]
+        assert abs(stats["cost_final"] - want_stats["cost_final"]) <= 1e-9 * want_stats["cost_final"]
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+        s.close()
+    side.close()

@@ -85,3 +85,22 @@ def test_loop_reference_scale_behaviour_runs(ctx, sequence, parking_params):
         base = vo.frame_queue.get(N_FRAMES - 1 - (k.idx - 3)).pose
         rel = np.asarray(k.pose, np.float64) @ hom_inv(np.asarray(base, np.float64))
         assert np.linalg.norm(rel[:3, 3]) == pytest.approx(1.0, abs=1e-3)
+
+
+@pytest.mark.parametrize("route", ["klt", "sift"])
+def test_keyframe_overlap_equals_the_sequential_order(ctx, sequence, parking_params, route):
+    """overlap_keyframe runs the two-view part of a keyframe's bootstrap on a second context while the window's trial
+    steps are in flight; neither reads the other's result, so keyframes, poses and landmarks must be those of the
+    reference's order (bundle adjustment, then bootstrap).  Float64 sums inside the solver land in atomics' order, so
+    the comparison is to 1e-9 rather than to the bit."""
+    scene, frames = sequence
+    runs = [_run(scene, frames[:45], rescale_bootstrap=True, bootstrap_correspondences=route, overlap_keyframe=flag)[0]
+            for flag in (True, False)]
+    a, b = runs
+    assert [k.idx for k in a.keyframes] == [k.idx for k in b.keyframes] and len(a.keyframes) >= 3
+    pa = np.array([np.asarray(f.pose, np.float64) for f in a.frame_queue.queue])
+    pb = np.array([np.asarray(f.pose, np.float64) for f in b.frame_queue.queue])
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-9)
+    la, lb = a.keypoint_trajectories.landmarks.array, b.keypoint_trajectories.landmarks.array
+    assert la.shape == lb.shape
+    np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-9)

@@ -32,6 +32,7 @@ SIGNATURES = {
     "vo_last_error": (ctypes.c_char_p, []),
     "vo_version": (ctypes.c_int, []),
     "vo_ctx_create": (ctypes.c_int, [ctypes.c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "vo_ctx_create_own_stream": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
     "vo_ctx_destroy": (ctypes.c_int, [c_vp]),
     "vo_sync": (ctypes.c_int, [c_vp]),
     "vo_dev_alloc": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
@@ -87,6 +88,9 @@ SIGNATURES = {
     "vo_ba_destroy": (None, [c_vp]),
     "vo_ba_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_vp, ctypes.c_int,
                                    c_vp]),
+    "vo_ba_solve_begin": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int]),
+    "vo_ba_solve_finish": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp]),
     "vo_ba_linearize": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_f64p]),
     "vo_ba_try_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_f64p, ctypes.POINTER(ctypes.c_int)]),
     "vo_ba_accept": (ctypes.c_int, [c_vp, c_vp]),

@@ -996,6 +996,8 @@ struct vo_ba {
            *Hpp[2] = {nullptr, nullptr}, *Hcp[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};
     int cur = 0;
     bool linearized = false, have_candidate = false;
+    bool solve_pending = false;   // between vo_ba_solve_begin and vo_ba_solve_finish
+    int solve_cap = 0, solve_queued = 0;     // trial steps the loop may take in all / queued so far
     BaCtl *ctl = nullptr;      // vo_ba_solve's bookkeeping record
     size_t slot_bytes = 0;     // one slot's {x, cost, Hcc, Hpp, Hcp, g} are one contiguous block of this size
     size_t lds_bytes = 0;  // n*n+2n doubles when the reduced system is kept in LDS, else 0
@@ -2929,16 +2931,37 @@ __global__ __launch_bounds__(256) void ba_lm_copy_kernel(const BaCtl *__restrict
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
-                           int stop_on_flat_reject, double *x_out, int mem, vo_ba_lm_stats *stats)
+// One round of queued trial steps behind the loop's record (each followed by the decision and the conditional copy).
+static int ba_solve_enqueue_round(vo_ba *ba, int batch)
 {
-    VO_REQUIRE(ctx && ba && x0 && x_out, "vo_ba_solve: NULL argument");
-    VO_REQUIRE(ba->ctx == ctx, "vo_ba_solve: solver belongs to another context");
-    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_solve: bad mem flag %d", mem);
-    VO_REQUIRE(max_iters >= 0 && ftol >= 0 && lambda0 > 0, "vo_ba_solve: max_iters=%d ftol=%g lambda0=%g", max_iters, ftol, lambda0);
+    vo_ctx *ctx = ba->ctx;
+    const int c = ba->cur, o = 1 - c;
+    const size_t n16 = ba->slot_bytes / 16;
+    unsigned copy_blocks = (unsigned)((n16 + 255) / 256);
+    if (copy_blocks > 4096) copy_blocks = 4096;
+    int rc;
+    for (int k = 0; k < batch; ++k) {
+        if ((rc = ba_try_step_enqueue(ba, 0.0, ba->ctl))) return rc;
+        hipLaunchKernelGGL(ba_lm_control_kernel, dim3(1), dim3(64), 0, ctx->stream, ba->ctl, (const double *)ba->cost[o], (const int *)ba->flag);
+        hipLaunchKernelGGL(ba_lm_copy_kernel, dim3(copy_blocks), dim3(256), 0, ctx->stream, (const BaCtl *)ba->ctl, (uint4 *)ba->x[c],
+                           (const uint4 *)ba->x[o], n16);
+        VO_HIP_CHECK(hipGetLastError());
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_ba_solve_begin(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
+                                 int stop_on_flat_reject, int first_round, int mem)
+{
+    VO_REQUIRE(ctx && ba && x0, "vo_ba_solve_begin: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_solve_begin: solver belongs to another context");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_solve_begin: bad mem flag %d", mem);
+    VO_REQUIRE(max_iters >= 0 && ftol >= 0 && lambda0 > 0, "vo_ba_solve_begin: max_iters=%d ftol=%g lambda0=%g", max_iters, ftol, lambda0);
+    VO_REQUIRE(first_round >= 0 && first_round <= 64, "vo_ba_solve_begin: first_round=%d", first_round);
+    if (ba->solve_pending) { vo_set_error("vo_ba_solve_begin: the previous solve of this solver has not been finished"); return VO_ESTATE; }
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
-    const int c = ba->cur, o = 1 - c;
+    const int c = ba->cur;
     if (mem == VO_MEM_HOST) VO_UPLOAD(ctx, ba->x[c], x0, np_ * 8);
     else VO_HIP_CHECK(hipMemcpyAsync(ba->x[c], x0, np_ * 8, hipMemcpyDeviceToDevice, ctx->stream));
     int rc = ba_linearize_into(ba, c);
@@ -2948,32 +2971,39 @@ extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_ite
     hipLaunchKernelGGL(ba_lm_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ba->ctl, (const double *)ba->cost[c], lambda0, ftol,
                        ba->O == 0 ? 0 : max_iters, stop_on_flat_reject);
     VO_HIP_CHECK(hipGetLastError());
-    BaCtl h = {};
-    const size_t n16 = ba->slot_bytes / 16;
-    unsigned copy_blocks = (unsigned)((n16 + 255) / 256);
-    if (copy_blocks > 4096) copy_blocks = 4096;
     // Trial steps are queued several at a time and the record read back once per round: a window of the frame loop
     // needs four to six of them, five most often.  A surplus step behind the one that ended the loop costs its
     // launches only (every kernel leaves on `done`), but at 30-40 launches that is 80 us.
-    const int cap = ba->O == 0 ? 0 : 10 * (max_iters > 0 ? max_iters : 1);
-    if (cap == 0) {
+    ba->solve_cap = ba->O == 0 ? 0 : 10 * (max_iters > 0 ? max_iters : 1);
+    // (a caller with other work to do meanwhile asks for a longer first round: steps behind the end of the loop then
+    // cost nothing it would see, and a second round would not be hidden)
+    if (first_round <= 0) first_round = 5;
+    ba->solve_queued = ba->solve_cap < first_round ? ba->solve_cap : first_round;
+    if ((rc = ba_solve_enqueue_round(ba, ba->solve_queued))) return rc;
+    ba->solve_pending = true;
+    return VO_OK;
+}
+
+extern "C" int vo_ba_solve_finish(vo_ctx *ctx, vo_ba *ba, double *x_out, int mem, vo_ba_lm_stats *stats)
+{
+    VO_REQUIRE(ctx && ba && x_out, "vo_ba_solve_finish: NULL argument");
+    VO_REQUIRE(ba->ctx == ctx, "vo_ba_solve_finish: solver belongs to another context");
+    VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_solve_finish: bad mem flag %d", mem);
+    if (!ba->solve_pending) { vo_set_error("vo_ba_solve_finish: no solve was begun on this solver"); return VO_ESTATE; }
+    VO_HIP_CHECK(hipSetDevice(ctx->device));
+    ba->solve_pending = false;
+    const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
+    const int c = ba->cur;
+    BaCtl h = {};
+    int rc;
+    for (;;) {
         VO_RESULT(ctx, &h, ba->ctl, sizeof(BaCtl));
         VO_RESULTS_FINISH(ctx);
-    }
-    for (int queued = 0, round = 0; queued < cap; ++round) {
-        int batch = round == 0 ? 5 : 3;
-        if (batch > cap - queued) batch = cap - queued;
-        for (int k = 0; k < batch; ++k) {
-            if ((rc = ba_try_step_enqueue(ba, 0.0, ba->ctl))) return rc;
-            hipLaunchKernelGGL(ba_lm_control_kernel, dim3(1), dim3(64), 0, ctx->stream, ba->ctl, (const double *)ba->cost[o], (const int *)ba->flag);
-            hipLaunchKernelGGL(ba_lm_copy_kernel, dim3(copy_blocks), dim3(256), 0, ctx->stream, (const BaCtl *)ba->ctl, (uint4 *)ba->x[c],
-                               (const uint4 *)ba->x[o], n16);
-            VO_HIP_CHECK(hipGetLastError());
-        }
-        queued += batch;
-        VO_RESULT(ctx, &h, ba->ctl, sizeof(BaCtl));
-        VO_RESULTS_FINISH(ctx);
-        if (h.done) break;
+        if (h.done || ba->solve_queued >= ba->solve_cap) break;
+        int batch = 3;
+        if (batch > ba->solve_cap - ba->solve_queued) batch = ba->solve_cap - ba->solve_queued;
+        if ((rc = ba_solve_enqueue_round(ba, batch))) return rc;
+        ba->solve_queued += batch;
     }
     if (mem == VO_MEM_HOST) {
         VO_RESULT(ctx, x_out, ba->x[c], np_ * 8);
@@ -2986,6 +3016,15 @@ extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_ite
         stats->trial_steps = h.trials; stats->accepted = h.accepted; stats->iterations = h.iters; stats->stop_reason = h.reason;
     }
     return VO_OK;
+}
+
+extern "C" int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
+                           int stop_on_flat_reject, double *x_out, int mem, vo_ba_lm_stats *stats)
+{
+    VO_REQUIRE(x_out != nullptr, "vo_ba_solve: NULL argument");
+    int rc = vo_ba_solve_begin(ctx, ba, x0, max_iters, ftol, lambda0, stop_on_flat_reject, 0, mem);
+    if (rc) return rc;
+    return vo_ba_solve_finish(ctx, ba, x_out, mem, stats);
 }
 
 extern "C" int vo_ba_accept(vo_ctx *ctx, vo_ba *ba)

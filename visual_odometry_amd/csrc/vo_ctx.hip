@@ -79,6 +79,23 @@ extern "C" int vo_ctx_create(int device, void *stream, vo_ctx **out)
     return VO_OK;
 }
 
+extern "C" int vo_ctx_create_own_stream(int device, vo_ctx **out)
+{
+    VO_REQUIRE(out != nullptr, "vo_ctx_create_own_stream: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    VO_HIP_CHECK(hipGetDeviceCount(&count));
+    VO_REQUIRE(device >= 0 && device < count, "vo_ctx_create_own_stream: device %d out of range (%d visible)", device, count);
+    VO_HIP_CHECK(hipSetDevice(device));
+    hipStream_t stream = nullptr;
+    // non-blocking: no implicit ordering with the device's default stream, which the default context works on
+    VO_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    int rc = vo_ctx_create(device, stream, out);
+    if (rc) { (void)hipStreamDestroy(stream); return rc; }
+    (*out)->owns_stream = true;
+    return VO_OK;
+}
+
 extern "C" int vo_ctx_destroy(vo_ctx *ctx)
 {
     if (!ctx) return VO_OK;
@@ -99,6 +116,7 @@ extern "C" int vo_ctx_destroy(vo_ctx *ctx)
     if (ctx->prof1) (void)hipEventDestroy(ctx->prof1);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VO_OK;
 }

@@ -37,6 +37,7 @@ struct vo_devbuf {
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false;    // created by vo_ctx_create_own_stream, destroyed with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vo_devbuf stage[10];         // 0-7: staging of host-side arguments; 8, 9: vo_track_pnp's block and generator states
     void *pinned = nullptr;      // page-locked host buffer for small read-backs (a copy into pageable memory blocks the caller)

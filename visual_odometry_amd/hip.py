@@ -114,6 +114,20 @@ class Context:
         _live_objects.add(self)
 
     @classmethod
+    def on_own_stream(cls, device: int = 0) -> "Context":
+        """Context on a new non-blocking HIP stream that the library owns (vo_ctx_create_own_stream): its work is not
+        ordered with the default context's, so the two can run side by side."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.vo_ctx_create_own_stream(int(device), ctypes.byref(h)), "vo_ctx_create_own_stream")
+        self.handle = h
+        self.device = int(device)
+        self._dev_pool = {}
+        _live_objects.add(self)
+        return self
+
+    @classmethod
     def from_torch(cls, device: int = 0) -> "Context":
         """Context on torch's current stream of `device` (so torch ops and events order with it)."""
         import torch
@@ -931,6 +945,24 @@ class BaSolver:
         st = _lib.BaLmStats()
         check(self.ctx.lib.vo_ba_solve(self.ctx.handle, self.handle, _ptr(x0), int(max_iters), float(ftol), float(lam0),
                                        int(bool(stop_on_flat_reject)), _ptr(x), VO_MEM_HOST, ctypes.byref(st)), "vo_ba_solve")
+        return x, {k: getattr(st, k) for k, _ in st._fields_}
+
+    def solve_begin(self, x0, max_iters: int = 50, ftol: float = 1e-4, lam0: float = 1e-3, stop_on_flat_reject: bool = True,
+                    first_round: int = 0) -> None:
+        """First half of solve (vo_ba_solve_begin): x0 goes up, the first round of trial steps is queued (first_round of
+        them; 0: the five that solve queues), nothing is waited for.  solve_finish returns the result; other contexts
+        may be used in between."""
+        x0 = np.ascontiguousarray(x0, np.float64).ravel()
+        if x0.size != 6 * self.F + 3 * self.P:
+            raise ValueError(f"BaSolver.solve_begin: parameter vector has {x0.size} entries, expected {6 * self.F + 3 * self.P}")
+        check(self.ctx.lib.vo_ba_solve_begin(self.ctx.handle, self.handle, _ptr(x0), int(max_iters), float(ftol), float(lam0),
+                                             int(bool(stop_on_flat_reject)), int(first_round), VO_MEM_HOST), "vo_ba_solve_begin")
+
+    def solve_finish(self):
+        """Second half of solve (vo_ba_solve_finish) -> (x (6F+3P) float64, stats)."""
+        x = np.empty(6 * self.F + 3 * self.P, np.float64)
+        st = _lib.BaLmStats()
+        check(self.ctx.lib.vo_ba_solve_finish(self.ctx.handle, self.handle, _ptr(x), VO_MEM_HOST, ctypes.byref(st)), "vo_ba_solve_finish")
         return x, {k: getattr(st, k) for k, _ in st._fields_}
 
     def params(self, candidate: bool = False) -> np.ndarray:

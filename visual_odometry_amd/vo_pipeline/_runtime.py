@@ -1,27 +1,47 @@
-"""Shared GPU context and pyramid cache of the drop-in classes."""
+"""Shared GPU contexts and pyramid cache of the drop-in classes."""
+import contextlib
 import weakref
 from typing import Dict, Optional, Tuple
 
 from .. import hip
 
-_pyr_cache: Dict[Tuple[int, int, int, int, int], list] = {}
+_pyr_cache: Dict[Tuple[int, int, int, int, int, int], list] = {}
+_side: Dict[int, hip.Context] = {}        # device -> the context on its own stream
+_active: Optional[hip.Context] = None     # what context() hands out while side_context() is entered
 
 
 def context(device: int = 0) -> hip.Context:
-    return hip.default_context(device)
+    return _active if _active is not None else hip.default_context(device)
+
+
+@contextlib.contextmanager
+def side_context(device: int = 0):
+    """Inside the block every drop-in class works on a second context with a HIP stream of its own, so that its GPU
+    work runs beside what the default context has queued instead of behind it (ContinuousVO builds a keyframe's
+    two-view bootstrap there while the bundle-adjustment window's trial steps run).  Host arrays in and out: nothing on
+    the device is shared between the two contexts."""
+    global _active
+    ctx = _side.get(device)
+    if ctx is None:
+        ctx = _side[device] = hip.Context.on_own_stream(device)
+    previous, _active = _active, ctx
+    try:
+        yield ctx
+    finally:
+        _active = previous
 
 
 def pyramid_pair(h: int, w: int, max_level: int, win: int = 21, device: int = 0):
     """Two reusable single-image pyramids for (h, w)."""
-    key = (device, h, w, max_level, win)
+    ctx = context(device)
+    key = (device, h, w, max_level, win, id(ctx))
     if key not in _pyr_cache:
-        ctx = context(device)
         _pyr_cache[key] = [hip.Pyramid(ctx, 1, h, w, max_level, win) for _ in range(2)]
     return _pyr_cache[key]
 
 
-# (device, h, w, max_level, win) -> (weak reference to the image whose pyramid sits in slot i, i)
-_last_next: Dict[Tuple[int, int, int, int, int], Tuple["weakref.ref", int]] = {}
+# (device, h, w, max_level, win, context) -> (weak reference to the image whose pyramid sits in slot i, i)
+_last_next: Dict[Tuple[int, int, int, int, int, int], Tuple["weakref.ref", int]] = {}
 
 
 def forget_pyramids() -> None:
@@ -37,7 +57,7 @@ def pyramids_for_pair(img0, img1, max_level: int, win: int = 21, device: int = 0
     defer_next: the pyramid of img1 is left to the caller, who must build it into the returned object
     (hip.track_pnp does, given the image) before anything else uses it."""
     h, w = img0.shape
-    key = (device, h, w, max_level, win)
+    key = (device, h, w, max_level, win, id(context(device)))
     pair = pyramid_pair(h, w, max_level, win, device)
     slot: Optional[int] = None
     if reuse and key in _last_next:

@@ -25,6 +25,29 @@ from .. import hip, params
 from . import _runtime
 
 
+class _AdjustmentInFlight:
+    """A window between BundleAdjustment.bundle_adjustment_begin and its result."""
+
+    def __init__(self, owner, pose_shape, landmark_shape, x, solver):
+        self.owner, self.pose_shape, self.landmark_shape, self.x, self.solver = owner, pose_shape, landmark_shape, x, solver
+
+    def finish(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(adjusted_M (F,3,4) float64, adjusted_landmarks (P,3) float64); waits for the window's trial steps."""
+        x, solver, self.solver = self.x, self.solver, None
+        if solver is not None:
+            try:
+                x, self.owner.last_stats = solver.solve_finish()
+            finally:
+                solver.close()
+        F = self.pose_shape[0]
+        cams = x[:6 * F].reshape(F, 6)
+        adjusted_M = np.zeros(self.pose_shape)
+        adjusted_M[:, :, 3] = cams[:, 3:]
+        if F:
+            adjusted_M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
+        return adjusted_M, x[6 * F:].reshape(self.landmark_shape).copy()
+
+
 class BundleAdjustment:
 
     def __init__(self, K: np.ndarray):
@@ -128,29 +151,40 @@ class BundleAdjustment:
                                 cost read-back per trial step
         :return (adjusted_M (F,3,4) float64, adjusted_landmarks (P,3) float64)
         """
+        return self.bundle_adjustment_begin(M, landmarks, camera_indices, point_indices, keypoints, max_iters, ftol,
+                                            stop_on_flat_reject, device_loop).finish()
+
+    def bundle_adjustment_begin(self, M: np.ndarray, landmarks: np.ndarray, camera_indices: np.ndarray,
+                                point_indices: np.ndarray, keypoints: np.ndarray,
+                                max_iters: int = 50, ftol: float = 1e-4, stop_on_flat_reject: bool = True,
+                                device_loop: bool = True, first_round: int = 0) -> "_AdjustmentInFlight":
+        """bundle_adjustment in two halves (not in the reference): this one builds the window's solver and queues its
+        first round of trial steps without waiting for them; `.finish()` of what it returns gives bundle_adjustment's
+        result.  In between the caller may run other GPU work on another context (_runtime.side_context); with
+        such work to hide behind it asks for a longer first round of queued trial steps (first_round, 0: five)."""
         camera_indices = np.asarray(camera_indices, np.int64)
         point_indices = np.asarray(point_indices, np.int64)
         F, P = M.shape[0], landmarks.shape[0]
         x = np.hstack((self._camera_params(M).ravel(), np.asarray(landmarks, np.float64).ravel()))
+        solver = None
         if camera_indices.size and F and P:
             # the outlier pre-filter of _preprocess_data, the compaction of what it keeps and the solver's observation
             # lists in one library call: the observations cross to the device once
             solver = hip.BaSolver.filtered(_runtime.context(), F, P, camera_indices, point_indices,
                                            keypoints, self.K, x, params.BA_DISTANCE_TH, int(F / 4) + 1)
-            if device_loop:
+            if not device_loop:
+                x = self._levenberg_marquardt(x, solver, max_iters, ftol, stop_on_flat_reject)      # closes the solver
+                solver = None
+            elif solver.O:
                 try:
-                    if solver.O:
-                        x, self.last_stats = solver.solve(x, max_iters, ftol, 1e-3, stop_on_flat_reject)
-                finally:
+                    solver.solve_begin(x, max_iters, ftol, 1e-3, stop_on_flat_reject, first_round)
+                except Exception:
                     solver.close()
+                    raise
             else:
-                x = self._levenberg_marquardt(x, solver, max_iters, ftol, stop_on_flat_reject)
-        cams = x[:6 * F].reshape(F, 6)
-        adjusted_M = np.zeros(M.shape)
-        adjusted_M[:, :, 3] = cams[:, 3:]
-        if F:
-            adjusted_M[:, :, :3] = Rotation.from_rotvec(cams[:, :3]).as_matrix()
-        return adjusted_M, x[6 * F:].reshape(landmarks.shape).copy()
+                solver.close()
+                solver = None
+        return _AdjustmentInFlight(self, M.shape, landmarks.shape, x, solver)
 
     def _levenberg_marquardt(self, x, solver, max_iters, ftol, stop_on_flat_reject=True):
         """The LM loop with the decisions on the host (what vo_ba_solve runs on the device): every trial step (Schur

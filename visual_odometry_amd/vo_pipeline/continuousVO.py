@@ -12,6 +12,7 @@ import numpy as np
 from .. import hip, params
 from ..utils.frameQueue import FrameQueue
 from ..utils.matrix import hom_inv
+from . import _runtime
 from .bootstrap import BootstrapInitializer
 from .bundleAdjustment import BundleAdjustment
 from .featureExtraction import ExtractorType, FeatureExtractor
@@ -124,12 +125,20 @@ class ContinuousVO:
 
     fused_step: a tracked frame's KLT, status filter and PnP run as one library call with one
     synchronisation (PoseEstimation.track_and_pose) instead of the reference's two calls with the filter
-    between them; the results are identical, False takes the two calls."""
+    between them; the results are identical, False takes the two calls.
+
+    overlap_keyframe: at a keyframe the reference adjusts the window and then bootstraps anew, one after the
+    other (continuousVO.py:223-236).  The GPU part of the bootstrap -- features or corners of the two views, their
+    correspondences, the fundamental matrix, the cheirality vote -- reads neither the window's result nor the
+    track store, so with True (default) it runs on a second context while the window's trial steps are in
+    flight on the first, and the host waits for the window only then; everything that touches poses, landmarks
+    and trajectories happens in the reference's order afterwards.  The results are those of the sequential
+    order (False)."""
 
     def __init__(self, dataset, descriptorType=ExtractorType.SIFT, matcherType=None, useKLT=True,
                  algo_method=AlgoMethod.P3P, max_point_distance: int = 100, frames_to_skip: int = 10,
                  frame_queue_size: int = 1000, rescale_bootstrap: bool = False,
-                 bootstrap_correspondences: str = "sift", fused_step: bool = True) -> None:
+                 bootstrap_correspondences: str = "sift", fused_step: bool = True, overlap_keyframe: bool = True) -> None:
         self.dataset = dataset
         self.descriptor = FeatureExtractor(descriptorType)
         self.matcher = matcherType
@@ -145,6 +154,7 @@ class ContinuousVO:
         self.rescale_bootstrap = rescale_bootstrap
         self.bootstrap_correspondences = bootstrap_correspondences
         self.fused_step = fused_step
+        self.overlap_keyframe = overlap_keyframe
         self.keypoint_trajectories = KeypointTrajectories()
         self.frame_idx = 0
         self.bootstrap_idx: List[int] = []
@@ -178,12 +188,17 @@ class ContinuousVO:
         self.frame_queue.add(frame_state)
         self._add_keyframe(frame_state)
 
+    def _bootstrap_views(self, baseline: FrameState, img: np.ndarray) -> BootstrapInitializer:
+        """The two-view reconstruction of (baseline, img): images in, relative pose and cloud out; it reads no pose and
+        nothing of the track store."""
+        return BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance,
+                                    correspondences=self.bootstrap_correspondences)
+
     def _bootstrap(self, baseline: FrameState, frame_idx: int, img: np.ndarray,
-                   world_transform: Optional[np.ndarray] = None) -> np.ndarray:
-        """Two-view initialisation between baseline and img; registers one trajectory per
-        triangulated point on frame_idx.  Returns the world -> camera transform of img."""
-        bootstrap = BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance,
-                                         correspondences=self.bootstrap_correspondences)
+                   world_transform: Optional[np.ndarray] = None, views: Optional[BootstrapInitializer] = None) -> np.ndarray:
+        """Two-view initialisation between baseline and img (`views`: already reconstructed); registers one
+        trajectory per triangulated point on frame_idx.  Returns the world -> camera transform of img."""
+        bootstrap = views if views is not None else self._bootstrap_views(baseline, img)
         T_rel = np.array(bootstrap.T)
         landmarks = np.array(bootstrap.point_cloud)
         if self.rescale_bootstrap and world_transform is not None:
@@ -254,10 +269,22 @@ class ContinuousVO:
                  n_tracked, ratio, uncertainty)
         if uncertainty > params.MAX_BASELINE_UNCERTAINTY or ratio < params.MIN_INLIER_RATIO:
             is_key = True
-            self._bundle_adjustment(frame_idx, T)
-            prev_keyframe = self.frame_queue.get(2)
+            views = None
+            if self.overlap_keyframe:
+                # eight trial steps up front: a window takes four to six, and what is queued behind its end is hidden by
+                # the bootstrap, which a second round of steps would not be
+                window = self._bundle_adjustment_begin(frame_idx, T, first_round=8)
+                prev_keyframe = self.frame_queue.get(2)
+                try:
+                    with _runtime.side_context():
+                        views = self._bootstrap_views(prev_keyframe, img)
+                finally:
+                    self._bundle_adjustment_finish(window)
+            else:
+                self._bundle_adjustment(frame_idx, T)
+                prev_keyframe = self.frame_queue.get(2)
             T = self._bootstrap(prev_keyframe, frame_idx, img,
-                                world_transform=T if self.rescale_bootstrap else prev_keyframe.pose)
+                                world_transform=T if self.rescale_bootstrap else prev_keyframe.pose, views=views)
             self.bootstrap_idx.append(frame_idx)
 
         frame_state = FrameState(frame_idx, img, T, tracked_kps=n_tracked, is_key=is_key)
@@ -296,8 +323,21 @@ class ContinuousVO:
                 ci, pi, keypoints, landmark_ids)
 
     def _bundle_adjustment(self, frame_idx: int, T: np.ndarray) -> np.ndarray:
+        return self._bundle_adjustment_finish(self._bundle_adjustment_begin(frame_idx, T))
+
+    def _bundle_adjustment_begin(self, frame_idx: int, T: np.ndarray, first_round: int = 0):
+        """The window ending at frame_idx handed to the solver, its trial steps queued (first_round of them, 0: the
+        solver's default); nothing is written back yet."""
         look_back, poses, landmarks, ci, pi, keypoints, landmark_ids = self._ba_window(frame_idx, T)
-        adjusted_poses, adjusted_landmarks = self.bundle_adjustment.bundle_adjustment(poses, landmarks, ci, pi, keypoints)
+        begin = getattr(self.bundle_adjustment, "bundle_adjustment_begin", None)
+        if begin is None:        # a solver with the reference's one call only
+            return look_back, landmark_ids, None, self.bundle_adjustment.bundle_adjustment(poses, landmarks, ci, pi, keypoints)
+        return look_back, landmark_ids, begin(poses, landmarks, ci, pi, keypoints, first_round=first_round), None
+
+    def _bundle_adjustment_finish(self, window) -> np.ndarray:
+        """Waits for the window and writes its poses and landmarks back (continuousVO.py:322-344)."""
+        look_back, landmark_ids, in_flight, done = window
+        adjusted_poses, adjusted_landmarks = in_flight.finish() if in_flight is not None else done
         hom = np.zeros((adjusted_poses.shape[0], 4, 4), adjusted_poses.dtype)
         hom[:, 0:3, :] = adjusted_poses
         hom[:, 3, 3] = 1
