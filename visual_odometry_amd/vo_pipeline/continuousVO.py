@@ -271,9 +271,9 @@ class ContinuousVO:
             is_key = True
             views = None
             if self.overlap_keyframe:
-                # eight trial steps up front: a window takes four to six, and what is queued behind its end is hidden by
-                # the bootstrap, which a second round of steps would not be
-                window = self._bundle_adjustment_begin(frame_idx, T, first_round=8)
+                # six trial steps up front instead of five: a window takes four to six, what is queued behind its end
+                # is hidden by the bootstrap, a second round of steps would not be (eight cost their launches: 0.1 ms)
+                window = self._bundle_adjustment_begin(frame_idx, T, first_round=6)
                 prev_keyframe = self.frame_queue.get(2)
                 try:
                     with _runtime.side_context():
