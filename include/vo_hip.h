@@ -315,7 +315,8 @@ int vo_ba_solve(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double 
  * two-view bootstrap (vo_pipeline/continuousVO.py:223-236: the adjustment, then the bootstrap) on a second context
  * while the window's trial steps run.  first_round: trial steps queued by _begin (0: five, what vo_ba_solve queues; a
  * caller that overlaps other work asks for more, a surplus step costing only its empty launches).  One solve at a time
- * per solver: a second _begin before _finish -> VO_ESTATE. */
+ * per solver: a second _begin before _finish, and vo_ba_linearize / _try_step / _accept / _params between the two
+ * (the queued loop owns the solver's two slots) -> VO_ESTATE. */
 int vo_ba_solve_begin(vo_ctx *ctx, vo_ba *ba, const double *x0, int max_iters, double ftol, double lambda0,
                       int stop_on_flat_reject, int first_round, int mem);
 int vo_ba_solve_finish(vo_ctx *ctx, vo_ba *ba, double *x_out, int mem, vo_ba_lm_stats *stats);

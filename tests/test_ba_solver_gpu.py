@@ -387,8 +387,8 @@ def test_device_side_loop_empty_and_frozen_windows(ctx):
 
 def test_solve_in_two_halves_and_its_state_errors(ctx):
     """vo_ba_solve_begin / _finish: the same result as the one call (to the order of the solver's float64 atomics), other
-    contexts usable in between, a longer first round changing nothing but the queue; a second begin before finish and a
-    finish without begin are state errors."""
+    contexts usable in between, a longer first round changing nothing but the queue; a second begin before finish, a
+    finish without begin and the step-by-step calls between the two are state errors."""
     from visual_odometry_amd import hip
     from visual_odometry_amd._lib import VoError
     pb = synth.ba_window_problem(F=30, births_every=5, per_birth=60, survive=0.9, seed=8)
@@ -406,6 +406,10 @@ def test_solve_in_two_halves_and_its_state_errors(ctx):
         s.solve_begin(x0, first_round=first_round)
         with pytest.raises(VoError):
             s.solve_begin(x0)
+        # the step-by-step calls are refused too while the queued loop owns the solver's slots
+        for call in (lambda: s.linearize(x0), lambda: s.try_step(1e-3), lambda: s.accept(), lambda: s.params()):
+            with pytest.raises(VoError, match="has not been finished"):
+                call()
         # another context does unrelated work on its own stream meanwhile
         r, cost = hip.ba_residual(side, x0, F, P, ci, pi, obs, K)
         assert np.isfinite(cost) and r.shape == (2 * ci.size,)

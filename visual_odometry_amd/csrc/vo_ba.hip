@@ -1728,7 +1728,10 @@ __device__ __forceinline__ bool solveb_triangle(double (&tv)[SOLVEB_MAX_W], doub
 // eliminated right-hand side to zf and the pivots' reciprocals to dinv, each written by one owner: the wave of
 // block 0 for the triangle, the diagonal block of a row range for the rows below.  A pivot that is not positive
 // clears flag[0], and later launches return at once.
-__global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w, double *A, double *b, double *__restrict__ Lf,
+// FULL: the panel has PANEL_MAX_W columns and rows start on 16-byte boundaries (n and k0 even), which every panel but a
+// window's last is: the column tests fold away and the rows come and go two entries per access.
+template <bool FULL>
+__global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w_arg, double *A, double *b, double *__restrict__ Lf,
                                                             double *__restrict__ zf, double *__restrict__ dinv,
                                                             int *__restrict__ flag, const BaCtl *__restrict__ ctl = nullptr)
 {
@@ -1736,26 +1739,35 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
     // whether there is anything to do is looked at after the panel's reads have been issued: tested first, the two
     // flags are a trip to memory of their own before every launch's real reads (20 launches a trial step)
     const int stop = (ctl ? ctl->done : 0) | (flag[0] == 0);
+    const int w = FULL ? PANEL_MAX_W : w_arg;
     const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     const int t0 = k0 + w, m = n - t0;          // trailing rows 0 .. m (row m: the right-hand side), columns 0 .. m-1
     int bi, bj;
     solveb_block_of(blockIdx.x, bi, bj);
     double tv[PANEL_MAX_W], v[PANEL_MAX_W];
-#pragma unroll
-    for (int c = 0; c < PANEL_MAX_W; ++c) tv[c] = (lane < w && c <= lane) ? A[(size_t)(k0 + lane) * n + k0 + c] : 0.0;
     const int lr = lane < 32 ? 32 * bi + lane : 32 * bj + lane - 32;
     const bool valid = lr <= m;
     const int i = t0 + lr;
     const double *src = i < n ? A + (size_t)i * n + k0 : b + k0;
-    // n, k0 and the first live column are even: a row's panel entries start on a 16-byte boundary
-    if (valid && ((n | k0) & 1) == 0) {
+    if (FULL) {
+        // a triangle row is read whole (its entries right of the diagonal lie inside the matrix and are dropped here)
+        const double *trow = A + (size_t)(k0 + (lane < PANEL_MAX_W ? lane : 0)) * n + k0;
 #pragma unroll
         for (int c = 0; c < PANEL_MAX_W; c += 2) {
-            const double2 two = c + 1 < w ? *(const double2 *)(src + c) : double2{c < w ? src[c] : 0.0, 0.0};
-            v[c] = two.x;
-            v[c + 1] = two.y;
+            const double2 two = *(const double2 *)(trow + c);
+            tv[c] = (lane < PANEL_MAX_W && c <= lane) ? two.x : 0.0;
+            tv[c + 1] = (lane < PANEL_MAX_W && c + 1 <= lane) ? two.y : 0.0;
+        }
+        const double *vrow = valid ? src : A + (size_t)k0 * n + k0;
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; c += 2) {
+            const double2 two = *(const double2 *)(vrow + c);
+            v[c] = valid ? two.x : 0.0;
+            v[c + 1] = valid ? two.y : 0.0;
         }
     } else {
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; ++c) tv[c] = (lane < w && c <= lane) ? A[(size_t)(k0 + lane) * n + k0 + c] : 0.0;
 #pragma unroll
         for (int c = 0; c < PANEL_MAX_W; ++c) v[c] = (valid && c < w) ? src[c] : 0.0;
     }
@@ -1767,19 +1779,19 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
     // and comes by a lane read that serves both; the columns stay unscaled (c_ik = L_ik d_k).
     double ft[PANEL_MAX_W], f[PANEL_MAX_W];
     bool bad = false;
-    // owners of what leaves the launch: block 0 for the triangle, the diagonal block of a row range for its rows
-    // (the factor's entries scaled, L_ik; the right-hand side as it is)
-    double *tri_out = blockIdx.x == 0 && lane < w ? Lf + (size_t)(k0 + lane) * n + k0 : nullptr;
-    double *row_out = bi == bj && lane < 32 && valid ? (i < n ? Lf + (size_t)i * n + k0 : zf + k0) : nullptr;
+    double my_id = 0.0;                                         // 1 / d_lane, for the lane that owns pivot `lane`
 #pragma unroll
     for (int c = 0; c < PANEL_MAX_W; ++c) {
+        ft[c] = f[c] = 0.0;
         if (c < w) {
+            // fused multiply-adds, written out (the file is built without contraction): half the vector
+            // instructions of this chain, which is what a launch's duration consists of
             double at = tv[c], av = v[c];
 #pragma unroll
             for (int q = 0; q < c; ++q) {
                 const double t = lane_read(tv[q], c);
-                at -= ft[q] * t;
-                av -= f[q] * t;
+                at = fma(-ft[q], t, at);
+                av = fma(-f[q], t, av);
             }
             tv[c] = at;
             v[c] = av;
@@ -1788,15 +1800,41 @@ __global__ __launch_bounds__(64) void ba_solve_panel_kernel(int n, int k0, int w
             const double id = fast_reciprocal(d);
             ft[c] = at * id;
             f[c] = av * id;
-            if (tri_out && c < lane) tri_out[c] = ft[c];
-            if (row_out) row_out[c] = i < n ? f[c] : av;
-            if (blockIdx.x == 0 && lane == c) dinv[k0 + c] = id;
+            my_id = lane == c ? id : my_id;
             tile[c * 64 + lane] = lane < 32 ? -f[c] : av;       // rows' side scaled by -1/d: the product comes out negative
         }
     }
     if (bad) {
         if (blockIdx.x == 0 && lane == 0) flag[0] = 0;
         return;
+    }
+    // What leaves the launch is written after the chain (inside it every entry was a store of its own behind a
+    // branch).  Owners: block 0 for the triangle and the pivots, the diagonal block of a row range for its rows (the
+    // factor's entries scaled, L_ik; the right-hand side as it is).
+    if (blockIdx.x == 0 && lane < w) {
+        dinv[k0 + lane] = my_id;
+        double *tri_out = Lf + (size_t)(k0 + lane) * n + k0;
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; c += 2) {
+            if (FULL && c + 1 < lane) *(double2 *)(tri_out + c) = double2{ft[c], ft[c + 1]};
+            else {
+                if (c < lane) tri_out[c] = ft[c];
+                if (c + 1 < lane) tri_out[c + 1] = ft[c + 1];
+            }
+        }
+    }
+    if (bi == bj && lane < 32 && valid) {
+        const bool fac = i < n;
+        double *row_out = fac ? Lf + (size_t)i * n + k0 : zf + k0;
+#pragma unroll
+        for (int c = 0; c < PANEL_MAX_W; c += 2) {
+            const double o0 = fac ? f[c] : v[c], o1 = fac ? f[c + 1] : v[c + 1];
+            if (FULL) *(double2 *)(row_out + c) = double2{o0, o1};
+            else {
+                if (c < w) row_out[c] = o0;
+                if (c + 1 < w) row_out[c + 1] = o1;
+            }
+        }
     }
     __syncthreads();
     vo_d4 acc[2][2];
@@ -2363,6 +2401,15 @@ static void ba_configure(vo_ba *ba)
     }
 }
 
+// Between vo_ba_solve_begin and vo_ba_solve_finish the solver's two slots and its record belong to the queued loop.
+#define BA_REFUSE_WHILE_SOLVING(ba, who)                                                                          \
+    do {                                                                                                          \
+        if ((ba)->solve_pending) {                                                                                \
+            vo_set_error("%s: a solve begun on this solver has not been finished (vo_ba_solve_finish)", who);     \
+            return VO_ESTATE;                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
 extern "C" void vo_ba_destroy(vo_ba *ba)
 {
     if (!ba) return;
@@ -2760,6 +2807,7 @@ extern "C" int vo_ba_linearize(vo_ctx *ctx, vo_ba *ba, const double *x, int mem,
 {
     VO_REQUIRE(ctx && ba && x && cost, "vo_ba_linearize: NULL argument");
     VO_REQUIRE(ba->ctx == ctx, "vo_ba_linearize: solver belongs to another context");
+    BA_REFUSE_WHILE_SOLVING(ba, "vo_ba_linearize");
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_linearize: bad mem flag %d", mem);
     VO_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t np_ = (size_t)ba->n + 3 * (size_t)ba->P;
@@ -2842,8 +2890,12 @@ static int ba_try_step_enqueue(vo_ba *ba, double lambda, const BaCtl *ctl)
                            ba->Hcc[c], ba->g[c], lambda, ba->zf, ba->dinv, ba->flag, ctl);
         for (int k0 = first; k0 < n; k0 += W) {
             const int w = n - k0 < W ? n - k0 : W, m = n - k0 - w, nb = (m + 1 + 31) / 32;
-            hipLaunchKernelGGL(ba_solve_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S, ba->rhs,
-                               ba->Lf, ba->zf, ba->dinv, ba->flag, ctl);
+            if (w == W && ((n | k0) & 1) == 0)
+                hipLaunchKernelGGL(ba_solve_panel_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S,
+                                   ba->rhs, ba->Lf, ba->zf, ba->dinv, ba->flag, ctl);
+            else
+                hipLaunchKernelGGL(ba_solve_panel_kernel<false>, dim3(nb * (nb + 1) / 2), dim3(64), 0, ctx->stream, n, k0, w, ba->S,
+                                   ba->rhs, ba->Lf, ba->zf, ba->dinv, ba->flag, ctl);
         }
         ba_backsolve_launch(ba, first, ba->Lf, ba->zf, ba->dinv, ba->Hcc[c], ctl);
     } else if (ba->solve_w) {
@@ -2866,6 +2918,7 @@ extern "C" int vo_ba_try_step(vo_ctx *ctx, vo_ba *ba, double lambda, double *cos
 {
     VO_REQUIRE(ctx && ba && cost_new && solved, "vo_ba_try_step: NULL argument");
     VO_REQUIRE(ba->ctx == ctx, "vo_ba_try_step: solver belongs to another context");
+    BA_REFUSE_WHILE_SOLVING(ba, "vo_ba_try_step");
     VO_REQUIRE(lambda >= 0, "vo_ba_try_step: lambda=%g", lambda);
     if (!ba->linearized) { vo_set_error("vo_ba_try_step: call vo_ba_linearize first"); return VO_ESTATE; }
     VO_HIP_CHECK(hipSetDevice(ctx->device));
@@ -3031,6 +3084,7 @@ extern "C" int vo_ba_accept(vo_ctx *ctx, vo_ba *ba)
 {
     VO_REQUIRE(ctx && ba, "vo_ba_accept: NULL argument");
     VO_REQUIRE(ba->ctx == ctx, "vo_ba_accept: solver belongs to another context");
+    BA_REFUSE_WHILE_SOLVING(ba, "vo_ba_accept");
     if (!ba->have_candidate) { vo_set_error("vo_ba_accept: no candidate step (call vo_ba_try_step first)"); return VO_ESTATE; }
     ba->cur = 1 - ba->cur;
     ba->have_candidate = false;
@@ -3041,6 +3095,7 @@ extern "C" int vo_ba_params(vo_ctx *ctx, vo_ba *ba, int candidate, double *x, in
 {
     VO_REQUIRE(ctx && ba && x, "vo_ba_params: NULL argument");
     VO_REQUIRE(ba->ctx == ctx, "vo_ba_params: solver belongs to another context");
+    BA_REFUSE_WHILE_SOLVING(ba, "vo_ba_params");
     VO_REQUIRE(mem == VO_MEM_HOST || mem == VO_MEM_DEVICE, "vo_ba_params: bad mem flag %d", mem);
     if (!ba->linearized || (candidate && !ba->have_candidate)) { vo_set_error("vo_ba_params: nothing to return yet"); return VO_ESTATE; }
     VO_HIP_CHECK(hipSetDevice(ctx->device));
