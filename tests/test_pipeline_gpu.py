@@ -104,3 +104,28 @@ def test_keyframe_overlap_equals_the_sequential_order(ctx, sequence, parking_par
     la, lb = a.keypoint_trajectories.landmarks.array, b.keypoint_trajectories.landmarks.array
     assert la.shape == lb.shape
     np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-9)
+
+
+def test_helper_thread_sift_equals_one_after_the_other(ctx, sequence, monkeypatch):
+    """The bootstrap's second SIFT call on a helper thread with a context of its own: the same keypoints, matches,
+    fundamental matrix and point cloud as with both calls on the caller's context, on two pairs in a row (the
+    helper's buffers are reused by the second) and under the keyframe overlap's side context."""
+    from visual_odometry_amd.vo_pipeline import _runtime
+    from visual_odometry_amd.vo_pipeline.bootstrap import BootstrapInitializer
+    scene, frames = sequence
+    K = np.asarray(scene.K, np.float64)
+
+    def pair(i, j):
+        b = BootstrapInitializer(frames[i][1], frames[j][1], K, correspondences="sift")
+        return b.F, b.pts1, b.pts2, b.T, b.point_cloud
+
+    results = {}
+    for flag in (True, False):
+        monkeypatch.setattr(_runtime, "helper_thread", flag)
+        results[flag] = [pair(0, 3), pair(2, 6)]
+        with _runtime.side_context():
+            results[flag].append(pair(1, 4))
+    for with_helper, without in zip(results[True], results[False]):
+        for a, b in zip(with_helper, without):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert len(results[True][0][1]) > 100

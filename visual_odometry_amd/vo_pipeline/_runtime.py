@@ -1,5 +1,7 @@
 """Shared GPU contexts and pyramid cache of the drop-in classes."""
+import concurrent.futures
 import contextlib
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -29,6 +31,25 @@ def side_context(device: int = 0):
         yield ctx
     finally:
         _active = previous
+
+
+# device -> (a context on a stream of its own, the one thread that works on it)
+_beside: Dict[int, Tuple[hip.Context, concurrent.futures.ThreadPoolExecutor]] = {}
+helper_thread = os.environ.get("VO_HELPER_THREAD", "1") != "0"
+
+
+def beside(fn, *args, device: int = 0, **kwargs) -> "concurrent.futures.Future":
+    """fn(ctx, *args, **kwargs) on a helper thread, with a context (and HIP stream) that only that thread uses, while
+    the caller goes on with a library call of its own: the library's calls release the interpreter lock, contexts
+    share nothing, and two calls that each alternate between short kernels and host work (two images' SIFT) fill each
+    other's gaps.  The result comes from `.result()` of the returned future; device arrays in it belong to the
+    helper's context and are complete when the call has returned (every library call ends synchronised)."""
+    entry = _beside.get(device)
+    if entry is None:
+        entry = _beside[device] = (hip.Context.on_own_stream(device),
+                                   concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="vo-helper"))
+    ctx, pool = entry
+    return pool.submit(fn, ctx, *args, **kwargs)
 
 
 def pyramid_pair(h: int, w: int, max_level: int, win: int = 21, device: int = 0):

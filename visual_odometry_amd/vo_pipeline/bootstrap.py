@@ -139,8 +139,20 @@ class BootstrapInitializer:
 
     def _estimate_fundamental(self, normalize=False):
         if self.features is None and self.correspondences == "sift":
-            k0, d0 = FeatureExtractor.sift_arrays(self.img1, device_descriptors=True)
-            k1, d1 = FeatureExtractor.sift_arrays(self.img2, device_descriptors=True)
+            if _runtime.helper_thread:
+                # the second image's SIFT on a helper thread and a stream of its own, beside the first image's
+                second = _runtime.beside(hip.sift_detect_compute, np.ascontiguousarray(self.img2, dtype=np.uint8),
+                                         device_descriptors=True, **FeatureExtractor.SIFT_ARGS)
+                try:
+                    k0, d0 = FeatureExtractor.sift_arrays(self.img1, device_descriptors=True)
+                finally:
+                    done = second.exception()       # waits: nothing of the helper's call is left running either way
+                if done is not None:
+                    raise done
+                k1, d1 = second.result()
+            else:
+                k0, d0 = FeatureExtractor.sift_arrays(self.img1, device_descriptors=True)
+                k1, d1 = FeatureExtractor.sift_arrays(self.img2, device_descriptors=True)
             self.features = (np.stack([k0["x"], k0["y"]], axis=1), d0, np.stack([k1["x"], k1["y"]], axis=1), d1)
         if self.features is not None:
             kp0, kp1, des0, des1 = self._matched_features()
