@@ -33,21 +33,23 @@ def side_context(device: int = 0):
         _active = previous
 
 
-# device -> (a context on a stream of its own, the one thread that works on it)
-_beside: Dict[int, Tuple[hip.Context, concurrent.futures.ThreadPoolExecutor]] = {}
+# (device, slot) -> (a context on a stream of its own, the one thread that works on it)
+_beside: Dict[Tuple[int, int], Tuple[hip.Context, concurrent.futures.ThreadPoolExecutor]] = {}
 helper_thread = os.environ.get("VO_HELPER_THREAD", "1") != "0"
 
 
-def beside(fn, *args, device: int = 0, **kwargs) -> "concurrent.futures.Future":
+def beside(fn, *args, device: int = 0, slot: int = 0, **kwargs) -> "concurrent.futures.Future":
     """fn(ctx, *args, **kwargs) on a helper thread, with a context (and HIP stream) that only that thread uses, while
-    the caller goes on with a library call of its own: the library's calls release the interpreter lock, contexts
-    share nothing, and two calls that each alternate between short kernels and host work (two images' SIFT) fill each
-    other's gaps.  The result comes from `.result()` of the returned future; device arrays in it belong to the
-    helper's context and are complete when the call has returned (every library call ends synchronised)."""
-    entry = _beside.get(device)
+    the caller goes on with work of its own: the library's calls release the interpreter lock, contexts share
+    nothing, and calls that each alternate between short kernels and host work (two images' SIFT, the assembly of a
+    bundle-adjustment window) fill each other's gaps.  `slot` names the helper: calls given to one slot run one after
+    the other, different slots side by side.  The result comes from `.result()` of the returned future; device
+    arrays in it belong to the helper's context and are complete when the call has returned (every library call ends
+    synchronised)."""
+    entry = _beside.get((device, slot))
     if entry is None:
-        entry = _beside[device] = (hip.Context.on_own_stream(device),
-                                   concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="vo-helper"))
+        entry = _beside[(device, slot)] = (hip.Context.on_own_stream(device),
+                                           concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="vo-helper"))
     ctx, pool = entry
     return pool.submit(fn, ctx, *args, **kwargs)
 

@@ -43,11 +43,35 @@ class _DescriptorRows:
         return self.source[rows].cpu().numpy()
 
 
+class _PendingSift:
+    """SIFT features of two images being computed on helper threads (BootstrapInitializer.sift_features_begin)."""
+
+    def __init__(self, first, second):
+        self.calls = (first, second)
+
+    def result(self):
+        """(kp0 (n,2), des0, kp1 (m,2), des1), descriptors as device arrays; waits for both calls."""
+        failed = [c.exception() for c in self.calls]        # waits: neither call is left running if one failed
+        for f in failed:
+            if f is not None:
+                raise f
+        (k0, d0), (k1, d1) = (c.result() for c in self.calls)
+        return np.stack([k0["x"], k0["y"]], axis=1), d0, np.stack([k1["x"], k1["y"]], axis=1), d1
+
+    def discard(self) -> None:
+        """Waits for the calls and drops what they return (the caller failed meanwhile)."""
+        for c in self.calls:
+            if c.exception() is None:
+                des = c.result()[1]
+                if des is not None:
+                    des.close()
+
+
 class BootstrapInitializer:
     def __init__(self, img1: np.ndarray, img2: np.ndarray, K: np.ndarray, max_point_dist: float = 100, features=None,
                  correspondences: str = "sift"):
         """features: optional (kp0, des0, kp1, des1) -- keypoints of the two images as (n,2) arrays of (x, y) or
-        sequences of objects with a `.pt`, and their (n,128) descriptors.  correspondences: "sift" (the reference's
+        sequences of objects with a `.pt`, and their (n,128) descriptors -- or what sift_features_begin returned.  correspondences: "sift" (the reference's
         route) or "klt" (corners + tracking), used when no features are given."""
         if correspondences not in ("sift", "klt"):
             raise ValueError(f"BootstrapInitializer: correspondences must be 'sift' or 'klt', got {correspondences!r}")
@@ -137,7 +161,19 @@ class BootstrapInitializer:
         logging.info(f"Bootstrapping features: ({len(des0)}, {len(des1)}), matches: {q.size}")
         return kp0[q], kp1[t], np.asarray(des0, np.float32)[q], np.asarray(des1, np.float32)[t]
 
+    @staticmethod
+    def sift_features_begin(img1: np.ndarray, img2: np.ndarray) -> _PendingSift:
+        """Starts the SIFT calls of a bootstrap's two images on two helper threads (contexts of their own) and
+        returns at once; hand the result to the constructor as `features`.  For a caller that has other work to do
+        before it needs the reconstruction -- ContinuousVO starts them before it assembles a keyframe's
+        bundle-adjustment window."""
+        calls = [_runtime.beside(hip.sift_detect_compute, np.ascontiguousarray(img, dtype=np.uint8), slot=slot,
+                                 device_descriptors=True, **FeatureExtractor.SIFT_ARGS) for slot, img in enumerate((img1, img2))]
+        return _PendingSift(*calls)
+
     def _estimate_fundamental(self, normalize=False):
+        if isinstance(self.features, _PendingSift):
+            self.features = self.features.result()
         if self.features is None and self.correspondences == "sift":
             if _runtime.helper_thread:
                 # the second image's SIFT on a helper thread and a stream of its own, beside the first image's

@@ -188,10 +188,11 @@ class ContinuousVO:
         self.frame_queue.add(frame_state)
         self._add_keyframe(frame_state)
 
-    def _bootstrap_views(self, baseline: FrameState, img: np.ndarray) -> BootstrapInitializer:
+    def _bootstrap_views(self, baseline: FrameState, img: np.ndarray, features=None) -> BootstrapInitializer:
         """The two-view reconstruction of (baseline, img): images in, relative pose and cloud out; it reads no pose and
-        nothing of the track store."""
-        return BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance,
+        nothing of the track store.  features: the two images' SIFT features already asked for
+        (BootstrapInitializer.sift_features_begin)."""
+        return BootstrapInitializer(baseline.img, img, self.K, max_point_dist=self.max_point_distance, features=features,
                                     correspondences=self.bootstrap_correspondences)
 
     def _bootstrap(self, baseline: FrameState, frame_idx: int, img: np.ndarray,
@@ -271,13 +272,23 @@ class ContinuousVO:
             is_key = True
             views = None
             if self.overlap_keyframe:
+                prev_keyframe = self.frame_queue.get(2)
+                features = None
+                if self.bootstrap_correspondences == "sift" and _runtime.helper_thread:
+                    # the bootstrap's two SIFT calls start on helper threads before the window is even assembled:
+                    # they need the two images only
+                    features = BootstrapInitializer.sift_features_begin(prev_keyframe.img, img)
                 # six trial steps up front instead of five: a window takes four to six, what is queued behind its end
                 # is hidden by the bootstrap, a second round of steps would not be (eight cost their launches: 0.1 ms)
-                window = self._bundle_adjustment_begin(frame_idx, T, first_round=6)
-                prev_keyframe = self.frame_queue.get(2)
+                try:
+                    window = self._bundle_adjustment_begin(frame_idx, T, first_round=6)
+                except Exception:
+                    if features is not None:
+                        features.discard()
+                    raise
                 try:
                     with _runtime.side_context():
-                        views = self._bootstrap_views(prev_keyframe, img)
+                        views = self._bootstrap_views(prev_keyframe, img, features)
                 finally:
                     self._bundle_adjustment_finish(window)
             else:
