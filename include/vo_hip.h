@@ -281,6 +281,12 @@ int vo_ba_create(vo_ctx *ctx, int F, int P, int O, const int64_t *ci, const int6
  * span exceeds 8 O + 1024: the caller numbers them by sorting instead); VO_EINVAL for a negative id. */
 int vo_ba_window_assemble(int F, const int32_t *counts, const float *const *kps, const int32_t *const *ids, int64_t *ci,
                           int64_t *pi, float *obs, int32_t *traj_of_point, int32_t *n_points);
+/* vo_ba_camera_params (host-side, no GPU work): the F window poses M (F x 3 x 4 float64, rows of [R|t]) as the
+ * solver's camera parameters (F x 6: rotation vector, translation), i.e. the per-frame cv.Rodrigues loop of
+ * BundleAdjustment.bundle_adjustment (vo_pipeline/bundleAdjustment.py:86-91).  As cv.Rodrigues does, the rotation
+ * block is first replaced by the nearest rotation (the poses may have been through float32); the rotation vector has
+ * length in [0, pi].  VO_EINVAL for a block that is singular, a reflection or not finite. */
+int vo_ba_camera_params(int F, const double *M, double *params);
 /* vo_ba_create_filtered: vo_ba_create preceded by the outlier pre-filter of BundleAdjustment._preprocess_data
  * (vo_pipeline/bundleAdjustment.py:111-134) on the device: obs is (O,2) float64, or float32 when obs_f32 is set (the
  * pipeline's keypoints, widened on the device exactly as the host conversion would); the residual is evaluated at x0

@@ -165,3 +165,38 @@ def test_window_assembler_equals_window_indices():
         hip.ba_window_assemble([np.zeros((2, 2), np.float32)], [np.array([3, -1], np.int32)])
     with pytest.raises(ValueError):
         hip.ba_window_assemble([np.zeros((3, 2), np.float32)], [np.array([3, 4], np.int32)])
+
+
+def test_camera_params_equal_scipy_rotation_vectors():
+    """vo_ba_camera_params (host-side): the rotation vector of every pose as scipy derives it from the matrix -- small
+    angles, half turns and the float32 poses the window hands over (orthonormal to 1e-7 only) included -- and the
+    translation column copied; singular blocks, reflections and NaN are refused."""
+    from scipy.spatial.transform import Rotation
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(4)
+    unit = rng.normal(size=(200, 3))
+    unit /= np.linalg.norm(unit, axis=1, keepdims=True)
+    for vectors in (rng.normal(size=(200, 3)), rng.normal(size=(200, 3)) * 1e-7, np.zeros((2, 3)), unit * np.pi,
+                    unit * (np.pi - 1e-5), unit * 3.0):
+        M = np.zeros((len(vectors), 3, 4))
+        M[:, :, :3] = Rotation.from_rotvec(vectors).as_matrix()
+        M[:, :, 3] = rng.normal(size=(len(vectors), 3))
+        got = hip.ba_camera_params(M)
+        np.testing.assert_allclose(got[:, :3], Rotation.from_matrix(M[:, :, :3]).as_rotvec(), rtol=0, atol=2e-15)
+        np.testing.assert_array_equal(got[:, 3:], M[:, :, 3])
+        assert (np.linalg.norm(got[:, :3], axis=1) <= np.pi + 1e-12).all()
+    M32 = M.astype(np.float32)
+    np.testing.assert_allclose(hip.ba_camera_params(M32)[:, :3], Rotation.from_matrix(M32[:, :, :3].astype(np.float64)).as_rotvec(),
+                               rtol=0, atol=1e-13)      # both project the float32 block onto the nearest rotation
+    assert hip.ba_camera_params(np.zeros((0, 3, 4))).shape == (0, 6)
+    bad = M.copy()
+    bad[3, 1, 1] = np.nan
+    with pytest.raises(ValueError, match="pose 3"):
+        hip.ba_camera_params(bad)
+    for block in (np.zeros((3, 3)), np.diag([1.0, 1.0, -1.0])):
+        bad = M.copy()
+        bad[5, :, :3] = block
+        with pytest.raises(ValueError, match="pose 5"):
+            hip.ba_camera_params(bad)
+    with pytest.raises(ValueError):
+        hip.ba_camera_params(np.zeros((2, 4, 4)))

@@ -85,6 +85,7 @@ SIGNATURES = {
                                              ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp),
                                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "vo_ba_window_assemble": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "vo_ba_camera_params": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp]),
     "vo_ba_destroy": (None, [c_vp]),
     "vo_ba_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_vp, ctypes.c_int,
                                    c_vp]),

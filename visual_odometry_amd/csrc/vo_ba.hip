@@ -2562,6 +2562,60 @@ extern "C" int vo_ba_window_assemble(int F, const int32_t *counts, const float *
     return VO_OK;
 }
 
+// ---- the window's poses as the solver's camera parameters (host) -------------------------------------------------
+// BundleAdjustment.bundle_adjustment turns every pose [R|t] into (rotation vector, t) with one cv.Rodrigues call per
+// frame (vo_pipeline/bundleAdjustment.py:86-91).  Here: unit quaternion by the largest-pivot rule (the trace or the
+// largest diagonal entry decides which component is formed from a sum, so nothing is divided by a small number up to
+// and including half turns), angle = 2 atan2(|v|, w) in [0, pi], vector = v * angle / sin(angle / 2) with the series
+// of that factor near zero.
+extern "C" int vo_ba_camera_params(int F, const double *M, double *params)
+{
+    VO_REQUIRE(F >= 0 && (F == 0 || (M && params)), "vo_ba_camera_params: NULL argument or F=%d", F);
+    for (int f = 0; f < F; ++f) {
+        const double *m = M + 12 * (size_t)f;            // rows of [R|t], four entries each
+        // cv.Rodrigues first replaces the block by the nearest rotation, U V^T of its singular value decomposition (the
+        // window's poses have been through float32: orthonormal to 1e-7 only).  That is the orthogonal factor of the
+        // polar decomposition, reached here by Newton's iteration R <- (R + R^-T) / 2: quadratic from a near-rotation
+        // (two or three rounds), still convergent from any nonsingular block.
+        double r[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        bool ok = true;
+        for (int it = 0; it < 60; ++it) {
+            const double c00 = r[4] * r[8] - r[5] * r[7], c01 = r[5] * r[6] - r[3] * r[8], c02 = r[3] * r[7] - r[4] * r[6];
+            const double det = r[0] * c00 + r[1] * c01 + r[2] * c02;
+            if (!(det > 0.0) || !std::isfinite(det)) { ok = false; break; }
+            // cofactors / det = inverse transposed
+            const double cof[9] = {c00, c01, c02,
+                                   r[2] * r[7] - r[1] * r[8], r[0] * r[8] - r[2] * r[6], r[1] * r[6] - r[0] * r[7],
+                                   r[1] * r[5] - r[2] * r[4], r[2] * r[3] - r[0] * r[5], r[0] * r[4] - r[1] * r[3]};
+            double change = 0.0;
+            for (int e = 0; e < 9; ++e) {
+                const double next = 0.5 * (r[e] + cof[e] / det);
+                change = fmax(change, fabs(next - r[e]));
+                r[e] = next;
+            }
+            if (change < 1e-15) break;
+        }
+        if (!ok) { vo_set_error("vo_ba_camera_params: pose %d: the rotation block is singular, a reflection or not finite", f); return VO_EINVAL; }
+        const double m00 = r[0], m01 = r[1], m02 = r[2], m10 = r[3], m11 = r[4], m12 = r[5], m20 = r[6], m21 = r[7], m22 = r[8];
+        const double tr = m00 + m11 + m22;
+        double x, y, z, w;
+        if (tr >= m00 && tr >= m11 && tr >= m22) { x = m21 - m12; y = m02 - m20; z = m10 - m01; w = 1.0 + tr; }
+        else if (m00 >= m11 && m00 >= m22) { x = 1.0 - tr + 2.0 * m00; y = m10 + m01; z = m20 + m02; w = m21 - m12; }
+        else if (m11 >= m22) { x = m01 + m10; y = 1.0 - tr + 2.0 * m11; z = m21 + m12; w = m02 - m20; }
+        else { x = m02 + m20; y = m12 + m21; z = 1.0 - tr + 2.0 * m22; w = m10 - m01; }
+        const double norm = sqrt(x * x + y * y + z * z + w * w);
+        if (!(norm > 0.0) || !std::isfinite(norm)) { vo_set_error("vo_ba_camera_params: pose %d: the rotation block is not finite", f); return VO_EINVAL; }
+        const double s = (w < 0 ? -1.0 : 1.0) / norm;
+        x *= s; y *= s; z *= s; w *= s;
+        const double angle = 2.0 * atan2(sqrt(x * x + y * y + z * z), w), a2 = angle * angle;
+        const double factor = angle <= 1e-3 ? 2.0 + a2 / 12.0 + 7.0 * a2 * a2 / 2880.0 : angle / sin(0.5 * angle);
+        double *o = params + 6 * (size_t)f;
+        o[0] = x * factor; o[1] = y * factor; o[2] = z * factor;
+        o[3] = m[3]; o[4] = m[7]; o[5] = m[11];
+    }
+    return VO_OK;
+}
+
 // ---- a window's solver built from raw observations: outlier pre-filter, compaction and lists on the device ----
 // BundleAdjustment._preprocess_data (vo_pipeline/bundleAdjustment.py:111-134) evaluates the residual at the start,
 // drops the observations whose squared reprojection error exceeds a threshold, and hands the rest to the solver.  Done

@@ -984,6 +984,17 @@ class BaSolver:
             pass
 
 
+def ba_camera_params(M) -> np.ndarray:
+    """Host-side (vo_ba_camera_params): window poses (F, 3, 4) -> the solver's camera parameters (F, 6) float64,
+    rotation vector and translation per frame (cv.Rodrigues of every rotation block)."""
+    M = np.ascontiguousarray(M, np.float64)
+    if M.ndim != 3 or M.shape[1:] != (3, 4):
+        raise ValueError("ba_camera_params: poses must be (F, 3, 4), got %s" % (M.shape,))
+    out = np.empty((M.shape[0], 6), np.float64)
+    check(_lib.load().vo_ba_camera_params(M.shape[0], _ptr(M), _ptr(out)), "vo_ba_camera_params")
+    return out
+
+
 def ba_window_assemble(kps_per_frame, ids_per_frame):
     """Host-side (vo_ba_window_assemble): the observation arrays of a bundle-adjustment window from per-frame lists of
     keypoints ((n_f, 2) float32) and trajectory ids ((n_f,) int32) -> (camera_indices (O,) int64 ascending,

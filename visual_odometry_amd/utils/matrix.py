@@ -33,3 +33,4 @@ def hom_inv(T: np.ndarray) -> np.ndarray:
 
 def to_hom(pts: np.ndarray) -> np.ndarray:
     return np.concatenate([pts, np.ones((pts.shape[0], 1), dtype=pts.dtype)], axis=1)
+

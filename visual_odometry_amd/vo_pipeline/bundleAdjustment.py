@@ -113,12 +113,8 @@ class BundleAdjustment:
 
     @staticmethod
     def _camera_params(M: np.ndarray) -> np.ndarray:
-        num_frames = M.shape[0]
-        camera_params = np.zeros((num_frames, 6))
-        camera_params[:, 3:6] = M[:, :, 3]
-        if num_frames:
-            camera_params[:, :3] = Rotation.from_matrix(np.asarray(M[:, :, :3], np.float64)).as_rotvec()
-        return camera_params
+        """(F, 6) rotation vector and translation of every pose (bundleAdjustment.py:86-91), in one host-side library call."""
+        return hip.ba_camera_params(M)
 
     def _preprocess_data(self, M, landmarks, camera_indices, point_indices, keypoints):
         """Drop observations whose squared reprojection error at the start exceeds BA_DISTANCE_TH."""
