@@ -88,22 +88,28 @@ def test_loop_reference_scale_behaviour_runs(ctx, sequence, parking_params):
 
 
 @pytest.mark.parametrize("route", ["klt", "sift"])
-def test_keyframe_overlap_equals_the_sequential_order(ctx, sequence, parking_params, route):
+def test_keyframe_overlap_equals_the_sequential_order(ctx, sequence, parking_params, route, monkeypatch):
     """overlap_keyframe runs the two-view part of a keyframe's bootstrap on a second context while the window's trial
-    steps are in flight; neither reads the other's result, so keyframes, poses and landmarks must be those of the
-    reference's order (bundle adjustment, then bootstrap).  Float64 sums inside the solver land in atomics' order, so
-    the comparison is to 1e-9 rather than to the bit."""
+    steps are in flight -- with helper threads on, the SIFT route's two feature calls start on threads of their own
+    even before the window is assembled; neither side reads the other's result, so keyframes, poses and landmarks
+    must be those of the reference's order (bundle adjustment, then bootstrap).  Float64 sums inside the solver land
+    in atomics' order, so the comparison is to 1e-9 rather than to the bit."""
+    from visual_odometry_amd.vo_pipeline import _runtime
     scene, frames = sequence
-    runs = [_run(scene, frames[:45], rescale_bootstrap=True, bootstrap_correspondences=route, overlap_keyframe=flag)[0]
-            for flag in (True, False)]
-    a, b = runs
-    assert [k.idx for k in a.keyframes] == [k.idx for k in b.keyframes] and len(a.keyframes) >= 3
-    pa = np.array([np.asarray(f.pose, np.float64) for f in a.frame_queue.queue])
+    runs = []
+    for overlap, helper in ((True, True), (True, False), (False, True)):
+        monkeypatch.setattr(_runtime, "helper_thread", helper)
+        runs.append(_run(scene, frames[:45], rescale_bootstrap=True, bootstrap_correspondences=route, overlap_keyframe=overlap)[0])
+    b = runs[-1]
     pb = np.array([np.asarray(f.pose, np.float64) for f in b.frame_queue.queue])
-    np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-9)
-    la, lb = a.keypoint_trajectories.landmarks.array, b.keypoint_trajectories.landmarks.array
-    assert la.shape == lb.shape
-    np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-9)
+    lb = b.keypoint_trajectories.landmarks.array
+    for a in runs[:-1]:
+        assert [k.idx for k in a.keyframes] == [k.idx for k in b.keyframes] and len(a.keyframes) >= 3
+        pa = np.array([np.asarray(f.pose, np.float64) for f in a.frame_queue.queue])
+        np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-9)
+        la = a.keypoint_trajectories.landmarks.array
+        assert la.shape == lb.shape
+        np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-9)
 
 
 def test_helper_thread_sift_equals_one_after_the_other(ctx, sequence, monkeypatch):

@@ -2,6 +2,7 @@
 import concurrent.futures
 import contextlib
 import os
+import threading
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -9,28 +10,36 @@ from .. import hip
 
 _pyr_cache: Dict[Tuple[int, int, int, int, int, int], list] = {}
 _side: Dict[int, hip.Context] = {}        # device -> the context on its own stream
-_active: Optional[hip.Context] = None     # what context() hands out while side_context() is entered
+_local = threading.local()                # .active: what context() hands out on this thread inside using() / side_context()
 
 
 def context(device: int = 0) -> hip.Context:
-    return _active if _active is not None else hip.default_context(device)
+    active = getattr(_local, "active", None)
+    return active if active is not None else hip.default_context(device)
+
+
+@contextlib.contextmanager
+def using(ctx: hip.Context):
+    """Inside the block every drop-in class called from this thread works on ctx."""
+    previous = getattr(_local, "active", None)
+    _local.active = ctx
+    try:
+        yield ctx
+    finally:
+        _local.active = previous
 
 
 @contextlib.contextmanager
 def side_context(device: int = 0):
-    """Inside the block every drop-in class works on a second context with a HIP stream of its own, so that its GPU
-    work runs beside what the default context has queued instead of behind it (ContinuousVO builds a keyframe's
-    two-view bootstrap there while the bundle-adjustment window's trial steps run).  Host arrays in and out: nothing on
-    the device is shared between the two contexts."""
-    global _active
+    """Inside the block every drop-in class (called from this thread) works on a second context with a HIP stream of
+    its own, so that its GPU work runs beside what the default context has queued instead of behind it
+    (ContinuousVO builds a keyframe's two-view bootstrap there while the bundle-adjustment window's trial steps run).
+    Host arrays in and out: nothing on the device is shared between the two contexts."""
     ctx = _side.get(device)
     if ctx is None:
         ctx = _side[device] = hip.Context.on_own_stream(device)
-    previous, _active = _active, ctx
-    try:
+    with using(ctx):
         yield ctx
-    finally:
-        _active = previous
 
 
 # (device, slot) -> (a context on a stream of its own, the one thread that works on it)

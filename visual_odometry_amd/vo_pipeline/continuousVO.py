@@ -37,14 +37,16 @@ def inlier_ratio(inliers: np.ndarray, inlier_count: int) -> float:
 def baseline_uncertainty(T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray) -> float:
     """|camera-centre displacement| / mean positive landmark depth in camera 0 (continuousVO.py:249-271);
     inf when no landmark has positive depth."""
-    T0_inv, T1_inv = hom_inv(T0), hom_inv(T1)
-    normal = T0[0:3, 0:3].T @ np.array([0.0, 0.0, 1.0])
-    centred = landmarks - T0_inv[0:3, 3]
-    d = centred @ normal
+    # the depth of X in camera 0 is the third row of its pose applied to X -- the reference's (X - C0) . (R0^T e3) with
+    # the centre C0 = -R0^T t0 multiplied out --, and the centres' distance needs no full inverse either: this runs
+    # on every tracked frame
+    T0, T1 = np.asarray(T0, np.float64), np.asarray(T1, np.float64)
+    d = landmarks @ T0[2, 0:3] + T0[2, 3]
     d = d[d > 0]
     if d.size == 0:
         return np.inf
-    return float(np.linalg.norm(T1_inv[:3, 3] - T0_inv[:3, 3]) / np.mean(d))
+    between = T0[0:3, 0:3].T @ T0[0:3, 3] - T1[0:3, 0:3].T @ T1[0:3, 3]
+    return float(np.sqrt(between @ between) / d.mean())
 
 
 def _tracked_frame_rows(status: np.ndarray, inlier_mask: np.ndarray):
@@ -275,8 +277,11 @@ class ContinuousVO:
                 prev_keyframe = self.frame_queue.get(2)
                 features = None
                 if self.bootstrap_correspondences == "sift" and _runtime.helper_thread:
-                    # the bootstrap's two SIFT calls start on helper threads before the window is even assembled:
-                    # they need the two images only
+                    # the bootstrap's two SIFT calls start on helper threads before the window is even assembled: they
+                    # need the two images only, and each is one long library call (the interpreter lock is free
+                    # meanwhile).  The rest of the two-view part stays on this thread: many short calls, which two
+                    # threads would only hand the lock back and forth for (measured: the KLT route's loop a quarter
+                    # slower with all of it on a helper).
                     features = BootstrapInitializer.sift_features_begin(prev_keyframe.img, img)
                 # six trial steps up front instead of five: a window takes four to six, what is queued behind its end
                 # is hidden by the bootstrap, a second round of steps would not be (eight cost their launches: 0.1 ms)
