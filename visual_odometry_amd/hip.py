@@ -958,9 +958,11 @@ class BaSolver:
         check(self.ctx.lib.vo_ba_solve_begin(self.ctx.handle, self.handle, _ptr(x0), int(max_iters), float(ftol), float(lam0),
                                              int(bool(stop_on_flat_reject)), int(first_round), VO_MEM_HOST), "vo_ba_solve_begin")
 
-    def solve_finish(self):
-        """Second half of solve (vo_ba_solve_finish) -> (x (6F+3P) float64, stats)."""
-        x = np.empty(6 * self.F + 3 * self.P, np.float64)
+    def solve_finish(self, workspace: Optional["HostWorkspace"] = None):
+        """Second half of solve (vo_ba_solve_finish) -> (x (6F+3P) float64, stats).  workspace: x is a view of its
+        buffer, valid until the next call with it."""
+        n = 6 * self.F + 3 * self.P
+        x = np.empty(n, np.float64) if workspace is None else workspace.take("solve x", n, np.float64)
         st = _lib.BaLmStats()
         check(self.ctx.lib.vo_ba_solve_finish(self.ctx.handle, self.handle, _ptr(x), VO_MEM_HOST, ctypes.byref(st)), "vo_ba_solve_finish")
         return x, {k: getattr(st, k) for k, _ in st._fields_}
@@ -995,12 +997,32 @@ def ba_camera_params(M) -> np.ndarray:
     return out
 
 
-def ba_window_assemble(kps_per_frame, ids_per_frame):
+class HostWorkspace:
+    """Host arrays that a caller fills again and again with results of growing size (a bundle-adjustment window per
+    keyframe): `take(name, n, dtype, width)` hands out the first n rows of a buffer kept under `name`, which grows
+    by doubling.  A fresh multi-megabyte numpy array is fresh pages from the kernel, every one a fault at its first
+    write -- more time than the pass that fills them; what take() returns is valid until the next take() of that name."""
+
+    def __init__(self):
+        self._buffers = {}
+
+    def take(self, name: str, n: int, dtype, width: int = 0) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        per_row = max(1, width)
+        buf = self._buffers.get(name)
+        if buf is None or buf.dtype != dtype or buf.size < n * per_row:
+            room = max(1 << 14, 2 * n * per_row)
+            buf = self._buffers[name] = np.empty(room, dtype)
+        out = buf[:n * per_row]
+        return out.reshape(n, width) if width else out
+
+
+def ba_window_assemble(kps_per_frame, ids_per_frame, workspace: Optional[HostWorkspace] = None):
     """Host-side (vo_ba_window_assemble): the observation arrays of a bundle-adjustment window from per-frame lists of
     keypoints ((n_f, 2) float32) and trajectory ids ((n_f,) int32) -> (camera_indices (O,) int64 ascending,
     point_indices (O,) int64, keypoints (O, 2) float32, trajectory id of every window landmark in order of first
     appearance (P,) int32), or None when the ids are too sparse for the library's table (the caller then numbers
-    them by sorting)."""
+    them by sorting).  workspace: the four arrays are views of its buffers, valid until the next call with it."""
     lib = _lib.load()
     F = len(ids_per_frame)
     if len(kps_per_frame) != F:
@@ -1022,8 +1044,12 @@ def ba_window_assemble(kps_per_frame, ids_per_frame):
     O = int(counts.sum())
     kp_ptrs = (ctypes.c_void_p * max(F, 1))(*[k.ctypes.data for k in kps])
     id_ptrs = (ctypes.c_void_p * max(F, 1))(*[t.ctypes.data for t in ids])
-    ci, pi = np.empty(O, np.int64), np.empty(O, np.int64)
-    obs, traj = np.empty((O, 2), np.float32), np.empty(O, np.int32)
+    if workspace is None:
+        ci, pi = np.empty(O, np.int64), np.empty(O, np.int64)
+        obs, traj = np.empty((O, 2), np.float32), np.empty(O, np.int32)
+    else:
+        ci, pi = workspace.take("window ci", O, np.int64), workspace.take("window pi", O, np.int64)
+        obs, traj = workspace.take("window obs", O, np.float32, 2), workspace.take("window traj", O, np.int32)
     n_points = ctypes.c_int32()
     rc = lib.vo_ba_window_assemble(F, _ptr(counts), ctypes.cast(kp_ptrs, ctypes.c_void_p), ctypes.cast(id_ptrs, ctypes.c_void_p),
                                    _ptr(ci), _ptr(pi), _ptr(obs), _ptr(traj), ctypes.byref(n_points))

@@ -36,7 +36,7 @@ class _AdjustmentInFlight:
         x, solver, self.solver = self.x, self.solver, None
         if solver is not None:
             try:
-                x, self.owner.last_stats = solver.solve_finish()
+                x, self.owner.last_stats = solver.solve_finish(self.owner._workspace)     # copied out below
             finally:
                 solver.close()
         F = self.pose_shape[0]
@@ -52,6 +52,7 @@ class BundleAdjustment:
 
     def __init__(self, K: np.ndarray):
         self.K = K
+        self._workspace = hip.HostWorkspace()       # the parameter vectors of a window, in and out: reused, not re-faulted
 
     # ---- residual pieces, same signatures as the reference ------------------
     def _rotate(self, points, rot_vecs):
@@ -161,7 +162,9 @@ class BundleAdjustment:
         camera_indices = np.asarray(camera_indices, np.int64)
         point_indices = np.asarray(point_indices, np.int64)
         F, P = M.shape[0], landmarks.shape[0]
-        x = np.hstack((self._camera_params(M).ravel(), np.asarray(landmarks, np.float64).ravel()))
+        x = self._workspace.take("start x", 6 * F + 3 * P, np.float64)
+        x[:6 * F] = self._camera_params(M).ravel()
+        x[6 * F:] = np.asarray(landmarks).reshape(-1)
         solver = None
         if camera_indices.size and F and P:
             # the outlier pre-filter of _preprocess_data, the compaction of what it keeps and the solver's observation
@@ -180,7 +183,8 @@ class BundleAdjustment:
             else:
                 solver.close()
                 solver = None
-        return _AdjustmentInFlight(self, M.shape, landmarks.shape, x, solver)
+        # without a solver in flight the start is the result: a copy, the workspace's buffer is the next window's
+        return _AdjustmentInFlight(self, M.shape, landmarks.shape, x if solver is not None else x.copy(), solver)
 
     def _levenberg_marquardt(self, x, solver, max_iters, ftol, stop_on_flat_reject=True):
         """The LM loop with the decisions on the host (what vo_ba_solve runs on the device): every trial step (Schur

@@ -328,15 +328,21 @@ class ContinuousVO:
             trajs.append(traj)
         # indices, concatenated keypoints and the landmark numbering in one pass of the library's host-side helper; ids too
         # sparse for its table (not what this pipeline produces) are numbered by window_indices
-        done = hip.ba_window_assemble(kps, trajs)
+        workspace = self.__dict__.setdefault("_window_workspace", hip.HostWorkspace())
+        done = hip.ba_window_assemble(kps, trajs, workspace)
         if done is not None:
             ci, pi, keypoints, traj_of_point = done
         else:
             ci, pi, traj_of_point = window_indices(trajs)
             keypoints = np.concatenate(kps).astype(np.float32).reshape(-1, 2)
         landmark_ids = store.traj2landmark.lookup(traj_of_point)
-        return (look_back, np.asarray(poses, dtype=np.float32), store.landmarks.array[landmark_ids].astype(np.float32),
-                ci, pi, keypoints, landmark_ids)
+        # the window's arrays live in buffers that are used again by the next window (they have been handed to the solver
+        # and uploaded by then): a window is megabytes, and fresh arrays of that size are page faults at every keyframe
+        landmarks = workspace.take("window landmarks", landmark_ids.size, np.float32, 3)
+        gathered = workspace.take("window landmarks f64", landmark_ids.size, np.float64, 3)
+        np.take(store.landmarks.array, landmark_ids, axis=0, out=gathered)
+        landmarks[...] = gathered
+        return look_back, np.asarray(poses, dtype=np.float32), landmarks, ci, pi, keypoints, landmark_ids
 
     def _bundle_adjustment(self, frame_idx: int, T: np.ndarray) -> np.ndarray:
         return self._bundle_adjustment_finish(self._bundle_adjustment_begin(frame_idx, T))
