@@ -185,10 +185,30 @@ class ContinuousVO:
 
     def _init_bootstrap(self, idx: int, img: np.ndarray) -> None:
         baseline = self.frame_queue.get(self.frames_to_skip - 1)
-        T = self._bootstrap(baseline, idx, img)
+        views = None
+        if self.overlap_keyframe:
+            # Set-up belongs to the first bootstrap, not to the first keyframe of the loop: done the way the keyframes
+            # do theirs -- feature calls on the helper threads, the rest on the second context --, it creates those
+            # contexts and sizes their buffers (page-locked rings, staging, scale spaces: several milliseconds of
+            # allocation calls); the tracker's pyramids and the solver's pool on the first context follow.
+            features = None
+            if self.bootstrap_correspondences == "sift" and _runtime.helper_thread:
+                features = BootstrapInitializer.sift_features_begin(baseline.img, img)
+            with _runtime.side_context():
+                views = self._bootstrap_views(baseline, img, features)
+            self._reserve(img)
+        T = self._bootstrap(baseline, idx, img, views=views)
         frame_state = FrameState(idx, img, T, is_key=True)
         self.frame_queue.add(frame_state)
         self._add_keyframe(frame_state)
+
+    def _reserve(self, img: np.ndarray) -> None:
+        """What the loop will need on the first context, allocated now: the two pyramids of the tracker for this image
+        size, and the bundle-adjustment pool (a one-observation solver, created and closed, leaves it behind)."""
+        h, w = img.shape[:2]
+        _runtime.pyramid_pair(h, w, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS)
+        one = np.zeros(1, np.int64)
+        hip.BaSolver(_runtime.context(), 1, 1, one, one, np.zeros((1, 2)), np.asarray(self.K, np.float64), 0).close()
 
     def _bootstrap_views(self, baseline: FrameState, img: np.ndarray, features=None) -> BootstrapInitializer:
         """The two-view reconstruction of (baseline, img): images in, relative pose and cloud out; it reads no pose and
