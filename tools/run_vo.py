@@ -196,6 +196,10 @@ def main():
                       "median_ms_per_tracked_frame": float(np.median(tracked) * 1e3),
                       "bootstrap_ms": float(per_frame[vo.frames_to_skip] * 1e3),
                       "ms_of_keyframe_steps": [round(float(per_frame[k.idx]) * 1e3, 3) for k in vo.keyframes[1:]],
+                      "slowest_other_steps": [(int(i), round(float(per_frame[i]) * 1e3, 3))
+                                              for i in sorted((i for i in range(vo.frames_to_skip + 1, len(per_frame))
+                                                               if i not in {k.idx for k in vo.keyframes}),
+                                                              key=lambda i: -per_frame[i])[:5]],
                       "rel_position_rms": rel, "max_rotation_deg": rot, "scale": scale,
                       "landmarks": len(vo.keypoint_trajectories.landmarks), **out_cpu,
                       **({"median_ms_of_parts": {k: float(np.median(v) * 1e3) for k, v in parts.items()},

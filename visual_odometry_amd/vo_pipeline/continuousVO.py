@@ -203,10 +203,18 @@ class ContinuousVO:
         self._add_keyframe(frame_state)
 
     def _reserve(self, img: np.ndarray) -> None:
-        """What the loop will need on the first context, allocated now: the two pyramids of the tracker for this image
-        size, and the bundle-adjustment pool (a one-observation solver, created and closed, leaves it behind)."""
+        """What the loop will need on the first context, allocated now: the tracker's pyramids for this image size and
+        the buffers of a tracked frame (eight points of the image tracked onto itself; the image's pyramid is then the
+        one the next frame starts from), and the bundle-adjustment pool (a one-observation solver, created and
+        closed, leaves it behind)."""
         h, w = img.shape[:2]
-        _runtime.pyramid_pair(h, w, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS)
+        corner = np.array([[w / 4, h / 4], [w / 2, h / 4], [3 * w / 4, h / 4], [w / 4, h / 2], [3 * w / 4, h / 2],
+                           [w / 4, 3 * h / 4], [w / 2, 3 * h / 4], [3 * w / 4, 3 * h / 4]], np.float32)
+        depth = np.hstack([corner, np.full((8, 1), 10.0, np.float32)])
+        if self.fused_step:
+            self.poseEstimator.track_and_pose(img, img, corner, depth, reuse_pyramids=True)
+        else:
+            PoseEstimation.KLT(img, img, corner, reuse_pyramids=True)
         one = np.zeros(1, np.int64)
         hip.BaSolver(_runtime.context(), 1, 1, one, one, np.zeros((1, 2)), np.asarray(self.K, np.float64), 0).close()
 
