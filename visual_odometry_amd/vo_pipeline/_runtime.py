@@ -47,14 +47,16 @@ _beside: Dict[Tuple[int, int], Tuple[hip.Context, concurrent.futures.ThreadPoolE
 helper_thread = os.environ.get("VO_HELPER_THREAD", "1") != "0"
 
 
-def beside(fn, *args, device: int = 0, slot: int = 0, **kwargs) -> "concurrent.futures.Future":
+def beside(fn, *args, device: Optional[int] = None, slot: int = 0, **kwargs) -> "concurrent.futures.Future":
     """fn(ctx, *args, **kwargs) on a helper thread, with a context (and HIP stream) that only that thread uses, while
     the caller goes on with work of its own: the library's calls release the interpreter lock, contexts share
     nothing, and calls that each alternate between short kernels and host work (two images' SIFT, the assembly of a
     bundle-adjustment window) fill each other's gaps.  `slot` names the helper: calls given to one slot run one after
     the other, different slots side by side.  The result comes from `.result()` of the returned future; device
     arrays in it belong to the helper's context and are complete when the call has returned (every library call ends
-    synchronised)."""
+    synchronised).  device: the helper's GPU (default: that of the caller's active context)."""
+    if device is None:
+        device = context().device           # the GPU the caller works on
     entry = _beside.get((device, slot))
     if entry is None:
         entry = _beside[(device, slot)] = (hip.Context.on_own_stream(device),

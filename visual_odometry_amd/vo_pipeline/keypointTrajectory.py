@@ -233,7 +233,7 @@ class KeypointTrajectories:
             lid = self.traj2landmark.lookup(ids)
             keep = lid >= 0
             if keep.all():
-                pts, kept = obs.pts.astype(np.float32), ids.astype(np.int32)
+                pts, kept = obs.pts.astype(np.float32, copy=False), ids.astype(np.int32)
             else:
                 pts, kept, lid = obs.pts[keep].astype(np.float32), ids[keep].astype(np.int32), lid[keep]
             obs.served = (self.traj2landmark.version, pts, kept, lid)
