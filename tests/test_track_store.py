@@ -200,3 +200,27 @@ def test_camera_params_equal_scipy_rotation_vectors():
             hip.ba_camera_params(bad)
     with pytest.raises(ValueError):
         hip.ba_camera_params(np.zeros((2, 4, 4)))
+
+
+def test_host_workspace_hands_out_views_of_growing_buffers():
+    """hip.HostWorkspace: the rows asked for, backed by one buffer per name that grows by doubling and is reused; the
+    window assembler fills such views with exactly what it returns in fresh arrays."""
+    from visual_odometry_amd import hip
+    ws = hip.HostWorkspace()
+    a = ws.take("a", 10, np.float32, 2)
+    assert a.shape == (10, 2) and a.dtype == np.float32
+    a[...] = 7
+    b = ws.take("a", 6, np.float32, 2)
+    assert b.shape == (6, 2) and np.shares_memory(a, b) and (b == 7).all()
+    big = ws.take("a", 100000, np.float32, 2)               # grows: a new buffer
+    assert big.shape == (100000, 2) and not np.shares_memory(a, big)
+    assert ws.take("a", 5, np.int64).dtype == np.int64 and ws.take("a", 0, np.int64).shape == (0,)
+    assert ws.take("other", 3, np.float64, 3).shape == (3, 3)
+    rng = np.random.default_rng(1)
+    ids = [np.sort(rng.choice(500, 120, replace=False)).astype(np.int32) for _ in range(9)]
+    kps = [rng.normal(size=(t.size, 2)).astype(np.float32) for t in ids]
+    fresh = hip.ba_window_assemble(kps, ids)
+    for _ in range(2):                                       # the second call reuses the first one's buffers
+        reused = hip.ba_window_assemble(kps, ids, ws)
+        for x, y in zip(fresh, reused):
+            np.testing.assert_array_equal(x, y)

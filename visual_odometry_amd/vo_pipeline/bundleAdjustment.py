@@ -52,7 +52,11 @@ class BundleAdjustment:
 
     def __init__(self, K: np.ndarray):
         self.K = K
-        self._workspace = hip.HostWorkspace()       # the parameter vectors of a window, in and out: reused, not re-faulted
+
+    @property
+    def _workspace(self) -> "hip.HostWorkspace":
+        """Host buffers of a window's parameter vectors, in and out: reused from window to window, not re-faulted."""
+        return self.__dict__.setdefault("_host_workspace", hip.HostWorkspace())
 
     # ---- residual pieces, same signatures as the reference ------------------
     def _rotate(self, points, rot_vecs):
