@@ -83,10 +83,27 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         counts = (int *)((char *)counts + b * bs.out);
     }
     for (int c = tid; c <= c0; c += FS_THREADS) counts[c] = 0;
+    // The landmarks of a single frame lie in page-locked host memory (they are read once, here): a read is a trip over
+    // the bus, and read inside the rounds below -- a barrier apart -- the trips of six rounds came one after the other,
+    // most of this kernel's time.  The first FS_AHEAD rounds' rows are therefore asked for up front, kept or not.
+    // (status and tracked points with them: device memory, but a miss in every round all the same)
+    constexpr int FS_AHEAD = 8;
+    float ahead[FS_AHEAD][5];
+    uint8_t ahead_status[FS_AHEAD];
+#pragma unroll
+    for (int r = 0; r < FS_AHEAD; ++r) {
+        const int i = r * FS_THREADS + tid;
+        ahead_status[r] = 0;
+        if (i < n) {
+            ahead_status[r] = status[i];
+            ahead[r][0] = X[3 * (int64_t)i]; ahead[r][1] = X[3 * (int64_t)i + 1]; ahead[r][2] = X[3 * (int64_t)i + 2];
+            ahead[r][3] = pts[2 * (int64_t)i]; ahead[r][4] = pts[2 * (int64_t)i + 1];
+        }
+    }
     int base = 0;
-    for (int i0 = 0, round = 0; i0 < n; i0 += FS_THREADS, ++round) {
+    auto compact_round = [&](int i0, int round, const float *mine, uint8_t mine_status) {
         const int i = i0 + tid;
-        const bool keep = i < n && status[i] == 1;
+        const bool keep = i < n && (mine ? mine_status : status[i]) == 1;
         if (i < n) full[i] = 0;
         const unsigned long long b = __ballot(keep);
         if (lane == 0) wcount[round & 1][wv] = __popcll(b);
@@ -100,12 +117,21 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         }
         if (keep) {
             const int64_t j = base + before + __popcll(b & ((1ull << lane) - 1));
-            Xc[3 * j] = X[3 * (int64_t)i]; Xc[3 * j + 1] = X[3 * (int64_t)i + 1]; Xc[3 * j + 2] = X[3 * (int64_t)i + 2];
-            xc[2 * j] = pts[2 * (int64_t)i]; xc[2 * j + 1] = pts[2 * (int64_t)i + 1];
+            if (mine) {
+                Xc[3 * j] = mine[0]; Xc[3 * j + 1] = mine[1]; Xc[3 * j + 2] = mine[2];
+                xc[2 * j] = mine[3]; xc[2 * j + 1] = mine[4];
+            } else {
+                Xc[3 * j] = X[3 * (int64_t)i]; Xc[3 * j + 1] = X[3 * (int64_t)i + 1]; Xc[3 * j + 2] = X[3 * (int64_t)i + 2];
+                xc[2 * j] = pts[2 * (int64_t)i]; xc[2 * j + 1] = pts[2 * (int64_t)i + 1];
+            }
             orig[j] = i;
         }
         base += total;
-    }
+    };
+#pragma unroll
+    for (int r = 0; r < FS_AHEAD; ++r)
+        if (r * FS_THREADS < n) compact_round(r * FS_THREADS, r, ahead[r], ahead_status[r]);
+    for (int i0 = FS_AHEAD * FS_THREADS, round = FS_AHEAD; i0 < n; i0 += FS_THREADS, ++round) compact_round(i0, round, nullptr, 0);
     if (wv != 0) return;
     const int m = base;
     if (lane == 0) {
