@@ -11,6 +11,7 @@
 #include <math.h>
 
 #define SOLVER_THREADS 64
+#define P3P_LANES 4           // lanes per sample in p3p_kernel, one per root of the quartic
 
 // ---- polynomial helpers ----------------------------------------------------------
 // real roots of x^3 + b x^2 + c x + d; returns their number (1 or 3), polished
@@ -47,7 +48,8 @@ __device__ static int cubic_roots(double b, double c, double d, double *x)
     return n;
 }
 
-// real roots of a4 x^4 + ... + a0 (a4 != 0) by Ferrari's factorisation; returns their number
+// real roots of a4 x^4 + ... + a0 (a4 != 0) by Ferrari's factorisation; returns their number.  The roots leave
+// unpolished and as roots of the depressed quartic: quartic_polish(x[i]) finishes root i.
 __device__ static int quartic_roots(double a4, double a3, double a2, double a1, double a0, double *x)
 {
     const double a = a3 / a4, b = a2 / a4, c = a1 / a4, d = a0 / a4;
@@ -80,16 +82,19 @@ __device__ static int quartic_roots(double a4, double a3, double a2, double a1, 
             if (d2 >= 0) { const double s = sqrt(d2); x[n++] = 0.5 * (beta + s); x[n++] = 0.5 * (beta - s); }
         }
     }
-    for (int i = 0; i < n; ++i) {
-        double v = x[i] - a_4;
-        for (int it = 0; it < 3; ++it) {
-            const double f = (((a4 * v + a3) * v + a2) * v + a1) * v + a0;
-            const double df = ((4.0 * a4 * v + 3.0 * a3) * v + 2.0 * a2) * v + a1;
-            if (df != 0) v -= f / df;
-        }
-        x[i] = v;
-    }
     return n;
+}
+
+// A root y of the depressed quartic as a root of the quartic itself, x = y - a3 / (4 a4), after three Newton steps.
+__device__ static double quartic_polish(double a4, double a3, double a2, double a1, double a0, double y)
+{
+    double v = y - 0.25 * (a3 / a4);
+    for (int it = 0; it < 3; ++it) {
+        const double f = (((a4 * v + a3) * v + a2) * v + a1) * v + a0;
+        const double df = ((4.0 * a4 * v + 3.0 * a3) * v + 2.0 * a2) * v + a1;
+        if (df != 0) v -= f / df;
+    }
+    return v;
 }
 
 __device__ static inline void cross3(const double *a, const double *b, double *o)
@@ -136,8 +141,12 @@ __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__rest
     // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
     // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
     __builtin_amdgcn_s_setprio(3);
-    const int s = samp_lo + blockIdx.x * SOLVER_THREADS + threadIdx.x;
-    if (s >= S) return;
+    // Four lanes to a sample, one per root of the quartic: every lane forms the quartic and its roots (the same
+    // instructions whether one lane or four execute them), then builds and judges the pose of its own root only, where
+    // a lane per sample walked up to four roots one after the other, each behind its own tests; the four compare
+    // their errors through shuffles.
+    const int s = samp_lo + (blockIdx.x * SOLVER_THREADS + threadIdx.x) / P3P_LANES, slot = threadIdx.x % P3P_LANES;
+    if (s >= S) return;                      // the lanes of a sample leave together
     {
         const size_t b = blockIdx.y;
         X = (const float *)((const char *)X + b * bs.work);
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__rest
         valid += b * bs.out;
         if (skip_bound) {
             skip_bound = (const int *)((const char *)skip_bound + b * bs.out);
-            if (s > *skip_bound) { valid[s] = 0; return; }
+            if (s > *skip_bound) { if (slot == 0) valid[s] = 0; return; }
         }
     }
     double P[4][3], j[3][3], obs3[2];
@@ -179,32 +188,35 @@ __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__rest
                                2 * (b2 - a2) / b2 * cg * cg);
         const double A1 = 4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg * cg * cb - (1 - p) * ca * cg);
         const double A0 = (1 + q) * (1 + q) - 4 * a2 / b2 * cg * cg;
-        double roots[4];
+        double roots[4] = {0.0, 0.0, 0.0, 0.0};
         int nr = 0;
         if (isfinite(A4) && isfinite(A3) && isfinite(A2) && isfinite(A1) && isfinite(A0) && fabs(A4) > 1e-300)
             nr = quartic_roots(A4, A3, A2, A1, A0, roots);
         double Tp[3][3];
         const bool tp_ok = triad(P[0], P[1], P[2], Tp);
-        for (int i = 0; i < nr && tp_ok; ++i) {
-            const double v = roots[i];
-            if (!(v > 0)) continue;
+        // this lane's root (a quartic has at most four, P3P_LANES of them)
+        const double raw = slot == 0 ? roots[0] : slot == 1 ? roots[1] : slot == 2 ? roots[2] : roots[3];
+        do {
+            if (!(slot < nr && tp_ok)) break;
+            const double v = quartic_polish(A4, A3, A2, A1, A0, raw);
+            if (!(v > 0)) break;
             const double den = 2 * (cg - v * ca);
-            if (fabs(den) < 1e-14) continue;
+            if (fabs(den) < 1e-14) break;
             const double u = ((q - 1) * v * v - 2 * q * cb * v + 1 + q) / den;
             const double dd = 1 + v * v - 2 * v * cb;
-            if (!(u > 0) || !(dd > 0)) continue;
+            if (!(u > 0) || !(dd > 0)) break;
             const double s1 = sqrt(b2 / dd), s2 = u * s1, s3 = v * s1;
             double Q[3][3];
             for (int c = 0; c < 3; ++c) { Q[0][c] = s1 * j[0][c]; Q[1][c] = s2 * j[1][c]; Q[2][c] = s3 * j[2][c]; }
             double Tq[3][3];
-            if (!triad(Q[0], Q[1], Q[2], Tq)) continue;
+            if (!triad(Q[0], Q[1], Q[2], Tq)) break;
             double R[3][3], t[3];
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 3; ++c) R[r][c] = Tq[r][0] * Tp[c][0] + Tq[r][1] * Tp[c][1] + Tq[r][2] * Tp[c][2];
             for (int r = 0; r < 3; ++r) t[r] = Q[0][r] - (R[r][0] * P[0][0] + R[r][1] * P[0][1] + R[r][2] * P[0][2]);
             double pc[3];
             for (int r = 0; r < 3; ++r) pc[r] = R[r][0] * P[3][0] + R[r][1] * P[3][1] + R[r][2] * P[3][2] + t[r];
-            if (!(pc[2] > 0)) continue;
+            if (!(pc[2] > 0)) break;
             const double w0 = K.k[0] * pc[0] + K.k[1] * pc[1] + K.k[2] * pc[2];
             const double w1 = K.k[3] * pc[0] + K.k[4] * pc[1] + K.k[5] * pc[2];
             const double w2 = K.k[6] * pc[0] + K.k[7] * pc[1] + K.k[8] * pc[2];
@@ -215,10 +227,27 @@ __global__ __launch_bounds__(SOLVER_THREADS) void p3p_kernel(const float *__rest
                 have = true;
                 for (int r = 0; r < 3; ++r) { bestRt[4 * r] = R[r][0]; bestRt[4 * r + 1] = R[r][1]; bestRt[4 * r + 2] = R[r][2]; bestRt[4 * r + 3] = t[r]; }
             }
-        }
+        } while (false);
     }
-    for (int k = 0; k < 12; ++k) Rt[12 * (int64_t)s + k] = have ? bestRt[k] : 0.0;
-    valid[s] = have ? 1 : 0;
+    // the smallest error of the four wins, the earlier root on equal errors: what walking the roots in order and
+    // keeping a strictly smaller error gives
+    double win_e = best_e;
+    int win = have ? slot : P3P_LANES;
+#pragma unroll
+    for (int d = 1; d < P3P_LANES; d <<= 1) {
+        const double other_e = __shfl_xor(win_e, d);
+        const int other = __shfl_xor(win, d);
+        if (other < P3P_LANES && (win == P3P_LANES || other_e < win_e || (other_e == win_e && other < win))) { win_e = other_e; win = other; }
+    }
+    if (win == P3P_LANES) {
+        if (slot == 0) {
+            for (int k = 0; k < 12; ++k) Rt[12 * (int64_t)s + k] = 0.0;
+            valid[s] = 0;
+        }
+    } else if (win == slot) {
+        for (int k = 0; k < 12; ++k) Rt[12 * (int64_t)s + k] = bestRt[k];
+        valid[s] = 1;
+    }
 }
 
 static inline double det3(const double *m)
@@ -363,7 +392,7 @@ extern "C" int vo_p3p_solve(vo_ctx *ctx, const float *X, const float *x, int n, 
         VO_UPLOAD(ctx, (void *)d_x, x, (size_t)n * 8);
         VO_UPLOAD(ctx, (void *)d_sub, subsets, (size_t)S * 16);
     }
-    hipLaunchKernelGGL(p3p_kernel, dim3((S + SOLVER_THREADS - 1) / SOLVER_THREADS), dim3(SOLVER_THREADS), 0, ctx->stream, d_X,
+    hipLaunchKernelGGL(p3p_kernel, dim3((P3P_LANES * S + SOLVER_THREADS - 1) / SOLVER_THREADS), dim3(SOLVER_THREADS), 0, ctx->stream, d_X,
                        d_x, n, Kv, Ki, d_sub, S, d_Rt, d_valid, vo_batch_strides(), 0, (const int *)nullptr);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
@@ -382,7 +411,7 @@ int vo_p3p_solve_dev(vo_ctx *ctx, const float *dX, const float *dx, int n, const
     memcpy(Kv.k, K, sizeof(Kv.k));
     VO_REQUIRE(invert3(K, Ki.k), "vo_p3p_solve: K is singular");
     VO_REQUIRE(bs.count <= 65535, "vo_p3p_solve: %d problems in one launch", bs.count);
-    hipLaunchKernelGGL(p3p_kernel, dim3((S - samp_lo + SOLVER_THREADS - 1) / SOLVER_THREADS, bs.count), dim3(SOLVER_THREADS), 0,
+    hipLaunchKernelGGL(p3p_kernel, dim3((P3P_LANES * (S - samp_lo) + SOLVER_THREADS - 1) / SOLVER_THREADS, bs.count), dim3(SOLVER_THREADS), 0,
                        ctx->stream, dX, dx, n, Kv, Ki, dsub, S, dRt, dvalid, bs, samp_lo, skip_bound_dev);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
