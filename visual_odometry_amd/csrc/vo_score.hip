@@ -12,7 +12,16 @@
 #include "vo_internal.h"
 
 #define SC_WAVES 4
-#define SC_CHUNK 1024  // points per wave
+#define SC_CHUNK 1024  // points per wave at most
+// Points per wave for a launch that would otherwise put `waves` wavefronts (hypotheses x problems) on the chip: few
+// hypotheses of one frame leave most of it idle while each wave walks a thousand points, sixteen dependent rounds of
+// loads; their points are then split further, down to two rounds per wave, and the shares added up with atomics.
+static int score_chunk(int n, int64_t waves)
+{
+    int chunk = SC_CHUNK;
+    while (chunk > 128 && waves * ((n + chunk - 1) / chunk) < 2048) chunk >>= 1;
+    return chunk;
+}
 
 __device__ __forceinline__ double std_max(double x, double y) { return (x < y) ? y : x; }
 
@@ -22,7 +31,8 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
                                                               double fx, double fy, double cx, double cy, float t,
                                                               int *__restrict__ counts, uint8_t *__restrict__ masks,
                                                               const int *__restrict__ n_dev, const int *__restrict__ first_dev,
-                                                              vo_batch_strides bs, int hyp_lo, const int *__restrict__ skip_bound)
+                                                              vo_batch_strides bs, int hyp_lo, const int *__restrict__ skip_bound,
+                                                              int chunk)
 {
     // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
     // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
@@ -54,8 +64,8 @@ __global__ __launch_bounds__(64 * SC_WAVES) void score_kernel(const float *__res
     double m[MS];
 #pragma unroll
     for (int k = 0; k < MS; ++k) m[k] = models[(first + h) * MS + k];
-    const int i0 = blockIdx.y * SC_CHUNK;
-    const int i1 = min(n, i0 + SC_CHUNK);
+    const int i0 = blockIdx.y * chunk;
+    const int i1 = min(n, i0 + chunk);
     if (i0 >= n && gridDim.y > 1) return;       // a chunk beyond a device-side point count adds nothing
     int good = 0;
     for (int i = i0 + lane; i < i1; i += 64) {
@@ -122,13 +132,14 @@ static int score_common(vo_ctx *ctx, const float *pa, const float *pb, int n, co
         VO_UPLOAD(ctx, (void *)d_m, models, (size_t)H * MS * 8);
     }
     if (PNP) memcpy(Kh, K, sizeof(Kh));  // K is always a host pointer: it travels as kernel arguments
-    const int chunks = n > 0 ? (n + SC_CHUNK - 1) / SC_CHUNK : 1;
+    const int chunk = score_chunk(n, H);
+    const int chunks = n > 0 ? (n + chunk - 1) / chunk : 1;
     VO_REQUIRE(chunks <= 65535, "%s: n=%d exceeds %d points", who, n, 65535 * SC_CHUNK);
     if (chunks > 1) VO_HIP_CHECK(hipMemsetAsync(d_c, 0, (size_t)H * 4, ctx->stream));
     dim3 grid((H + SC_WAVES - 1) / SC_WAVES, chunks);
     hipLaunchKernelGGL(score_kernel<PNP>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, d_pa, d_pb, n, d_m, H, Kh[0], Kh[4],
                        Kh[2], Kh[5], t, d_c, d_k, (const int *)nullptr, (const int *)nullptr, vo_batch_strides(), 0,
-                       (const int *)nullptr);
+                       (const int *)nullptr, chunk);
     VO_HIP_CHECK(hipGetLastError());
     if (mem == VO_MEM_HOST) {
         VO_RESULT(ctx, counts, d_c, (size_t)H * 4);
@@ -160,14 +171,16 @@ int vo_score_pnp_dev(vo_ctx *ctx, const float *dX, const float *dx, int n_cap, c
                      bool counts_cleared, const vo_batch_strides &bs, int hyp_lo, const int *skip_bound_dev)
 {
     if (H <= hyp_lo || bs.count <= 0) return VO_OK;
-    const int chunks = n_cap > 0 ? (n_cap + SC_CHUNK - 1) / SC_CHUNK : 1;
+    // without cleared counts a split costs a memset launch: more than it saves on the chains that call this
+    const int chunk = counts_cleared ? score_chunk(n_cap, (int64_t)(H - hyp_lo) * bs.count) : SC_CHUNK;
+    const int chunks = n_cap > 0 ? (n_cap + chunk - 1) / chunk : 1;
     VO_REQUIRE(chunks <= 65535 && bs.count <= 65535, "vo_score_pnp: n=%d exceeds %d points (or %d problems)", n_cap, 65535 * SC_CHUNK, bs.count);
     VO_REQUIRE(bs.count == 1 || (counts_cleared && !dmasks && !first_dev), "vo_score_pnp: batched scoring wants cleared counts and no masks");
     if (chunks > 1 && !counts_cleared) VO_HIP_CHECK(hipMemsetAsync(dcounts, 0, (size_t)H * 4, ctx->stream));
     const float t = (float)(thr * thr);
     dim3 grid((H - hyp_lo + SC_WAVES - 1) / SC_WAVES, chunks, bs.count);
     hipLaunchKernelGGL(score_kernel<true>, grid, dim3(64 * SC_WAVES), 0, ctx->stream, dX, dx, n_cap, dRt, H, K[0], K[4], K[2],
-                       K[5], t, dcounts, dmasks, n_dev, first_dev, bs, hyp_lo, skip_bound_dev);
+                       K[5], t, dcounts, dmasks, n_dev, first_dev, bs, hyp_lo, skip_bound_dev, chunk);
     VO_HIP_CHECK(hipGetLastError());
     return VO_OK;
 }
