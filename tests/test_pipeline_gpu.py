@@ -135,3 +135,34 @@ def test_helper_thread_sift_equals_one_after_the_other(ctx, sequence, monkeypatc
         for a, b in zip(with_helper, without):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     assert len(results[True][0][1]) > 100
+
+
+def test_fused_tracked_frame_equals_the_two_calls(ctx, sequence, parking_params):
+    """PoseEstimation.track_and_pose against KLT followed by PnP on the surviving rows (what the reference's
+    _process_frame does, continuousVO.py:160-180): same points, status, pose and inlier list; the inlier count the
+    loop reads instead of the list is the list's length; and the loop run with fused_step on and off lands on the
+    same keyframes and poses."""
+    from visual_odometry_amd.vo_pipeline.poseEstimation import AlgoMethod, PoseEstimation
+    scene, frames = sequence
+    vo, _ = _run(scene, frames[:14], rescale_bootstrap=True, bootstrap_correspondences="klt")
+    store = vo.keypoint_trajectories
+    kps, _, landmarks = store.at_frame(store.latest_frame)
+    img0, img1 = frames[13][1], frames[14][1]
+    est = PoseEstimation(np.asarray(scene.K, np.float64), use_KLT=True, algo_method_type=AlgoMethod.P3P)
+    pts, st, M, inliers = est.track_and_pose(img0, img1, kps, landmarks)
+    assert M is not None and est.last_inlier_count == inliers.shape[0] > 50
+    assert int(est.last_inlier_mask.sum()) == est.last_inlier_count
+    pts2, st2 = PoseEstimation.KLT(img0, img1, kps)
+    np.testing.assert_array_equal(pts, pts2)
+    np.testing.assert_array_equal(st, st2)
+    ok = st2.ravel() == 1
+    M2, inliers2 = est.PnP(landmarks[ok], pts2[ok])
+    np.testing.assert_array_equal(inliers.ravel(), np.asarray(inliers2).ravel())
+    np.testing.assert_allclose(M, M2, rtol=0, atol=1e-12)
+    assert est.track_and_pose(img0, img1, kps, landmarks, want_inliers=False)[3] is None
+    a = _run(scene, frames[:40], rescale_bootstrap=True, bootstrap_correspondences="klt", fused_step=True)[0]
+    b = _run(scene, frames[:40], rescale_bootstrap=True, bootstrap_correspondences="klt", fused_step=False)[0]
+    assert [k.idx for k in a.keyframes] == [k.idx for k in b.keyframes]
+    pa = np.array([np.asarray(f.pose, np.float64) for f in a.frame_queue.queue])
+    pb = np.array([np.asarray(f.pose, np.float64) for f in b.frame_queue.queue])
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-9)

@@ -224,3 +224,51 @@ def test_host_workspace_hands_out_views_of_growing_buffers():
         reused = hip.ba_window_assemble(kps, ids, ws)
         for x, y in zip(fresh, reused):
             np.testing.assert_array_equal(x, y)
+
+
+def test_continue_rows_equals_tracked_to_many():
+    """continue_rows (the tracked frame's path: ids and landmark links taken from the previous frame's answer) leaves
+    the store exactly as tracked_to_many with those ids does, and falls back to it when the previous answer is stale
+    or the frame already has observations."""
+    rng = np.random.default_rng(3)
+    T = np.eye(4)
+
+    def build(use_rows):
+        store = KeypointTrajectories()
+        store.landmarks.extend(rng0.normal(size=(40, 3)))
+        store.create_trajectories(5, rng0.normal(size=(40, 2)).astype(np.float32), T, np.arange(40))
+        frame = 5
+        for step in range(3):
+            kp, ids, lm = store.at_frame(frame)
+            rows = np.sort(rng0.choice(kp.shape[0], kp.shape[0] - 4, replace=False))
+            pts = (kp[rows] + 0.5).astype(np.float32)
+            if use_rows:
+                store.continue_rows(frame, rows, frame + 1, pts, T)
+            else:
+                store.tracked_to_many(ids[rows], frame + 1, pts, T)
+            frame += 1
+        # a frame that already has observations: the general path
+        kp, ids, _ = store.at_frame(frame)
+        extra = np.arange(2)
+        if use_rows:
+            store.continue_rows(frame, extra, frame, kp[extra] + 1, T)
+        else:
+            store.tracked_to_many(ids[extra], frame, kp[extra] + 1, T)
+        return store
+
+    stores = []
+    for use_rows in (True, False):
+        rng0 = np.random.default_rng(3)
+        stores.append(build(use_rows))
+    a, b = stores
+    assert a.latest_frame == b.latest_frame == 8
+    for f in range(5, 9):
+        for x, y in zip(a.at_frame(f), b.at_frame(f)):
+            np.testing.assert_array_equal(x, y)
+            assert x.dtype == y.dtype
+        np.testing.assert_array_equal(a.on_frame[f].ids, b.on_frame[f].ids)
+        np.testing.assert_array_equal(a.on_frame[f].pts, b.on_frame[f].pts)
+    for t in (0, 7, 39):
+        ta, tb = a.trajectory(t), b.trajectory(t)
+        assert (ta.init_idx, ta.final_idx) == (tb.init_idx, tb.final_idx)
+        np.testing.assert_array_equal(np.asarray(ta.pts), np.asarray(tb.pts))

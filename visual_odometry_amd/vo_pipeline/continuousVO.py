@@ -251,7 +251,8 @@ class ContinuousVO:
     def _process_frame(self, frame_idx: int, img: np.ndarray) -> None:
         store = self.keypoint_trajectories
         prev_img = self.frame_queue.get_head().img
-        prev_keypoints, prev_trajectories, prev_landmarks = store.at_frame(store.latest_frame)
+        from_frame = store.latest_frame
+        prev_keypoints, prev_trajectories, prev_landmarks = store.at_frame(from_frame)
 
         # the queue's images are never written to: the pyramid built for prev_img one step ago is kept
         T = None
@@ -259,7 +260,7 @@ class ContinuousVO:
             # tracker, filter and PnP in one library call; a frame with too few survivors (or no pose) falls
             # through to the forced bootstrap exactly as below
             tracked_pts, status, T, inliers = self.poseEstimator.track_and_pose(prev_img, img, prev_keypoints, prev_landmarks,
-                                                                                reuse_pyramids=True)
+                                                                                reuse_pyramids=True, want_inliers=False)
         else:
             tracked_pts, status = PoseEstimation.KLT(prev_img, img, prev_keypoints, reuse_pyramids=True)
         if self.fused_step and T is not None:
@@ -276,7 +277,9 @@ class ContinuousVO:
             if not self.fused_step:
                 T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
             assert T is not None, "PNP RANSAC was not able to compute a pose from 2D - 3D correspondences"
-            ratio = inlier_ratio(inliers, self.inlier_count)
+            # the fused call reports the number of inliers; their list is not formed for the ratio alone
+            ratio = inlier_ratio(inliers, self.inlier_count) if inliers is not None else \
+                self.poseEstimator.last_inlier_count / self.inlier_count
         else:
             warnings.warn("too few points, forced bootstrap")
             prev_keyframe = self.keyframes[-1]
@@ -288,7 +291,7 @@ class ContinuousVO:
             return
 
         if rows is not None:
-            store.tracked_to_many(prev_trajectories[rows], frame_idx, tracked_pts[rows], T)
+            store.continue_rows(from_frame, rows, frame_idx, tracked_pts[rows], T)
         else:
             keep = np.unique(inliers.ravel())       # ascending: the order the reference visits them in
             store.tracked_to_many(trajectories[keep], frame_idx, tracked_pts[keep], T)

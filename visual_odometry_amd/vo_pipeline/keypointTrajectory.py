@@ -197,6 +197,28 @@ class KeypointTrajectories:
             self._frame(frame_idx).add(ids, pts.copy())
         self._next_frame(frame_idx)
 
+    def continue_rows(self, from_frame: int, rows: np.ndarray, frame_idx: int, pts: np.ndarray, transform: np.ndarray) -> None:
+        """tracked_to_many for the trajectories at rows `rows` of what at_frame(from_frame) last returned (not in the
+        reference): their ids and landmark links are known from that answer, so what at_frame(frame_idx) will be asked
+        for is set up here instead of being looked up again -- the tracked frame's path through the store."""
+        served = self.on_frame[from_frame].served if from_frame in self.on_frame else None
+        fresh = frame_idx not in self.on_frame or len(self.on_frame[frame_idx]._ids) == 0
+        if served is None or served[0] != self.traj2landmark.version or not fresh:
+            ids = self.at_frame(from_frame, with_landmarks=False)[1][rows]
+            return self.tracked_to_many(ids, frame_idx, pts, transform)
+        _, _, ids32, lid = served
+        ids32, lid = ids32[rows], lid[rows]
+        pts = np.array(pts, np.float32).reshape(-1, 2)          # the store's own copy
+        assert ids32.shape[0] == pts.shape[0]
+        if ids32.size:
+            ids = ids32.astype(np.int64)
+            self._span.view[ids, 1] = frame_idx
+            self._tf.view[ids, 1] = self._transform_id(transform)
+            obs = self._frame(frame_idx)
+            obs.add(ids, pts)
+            obs.served = (self.traj2landmark.version, pts, ids32, lid)
+        self._next_frame(frame_idx)
+
     def create_trajectory(self, frame_idx: int, pt: np.ndarray, transform: np.ndarray,
                           landmark_id: Optional[int] = None) -> Tuple[Trajectory, int]:
         lid = None if landmark_id is None else np.array([landmark_id])

@@ -63,7 +63,7 @@ class PoseEstimation:
         return M, inliers
 
     def track_and_pose(self, img0: np.ndarray, img1: np.ndarray, prev_kpts: np.ndarray, pointcloud: np.ndarray,
-                       reuse_pyramids: bool = False):
+                       reuse_pyramids: bool = False, want_inliers: bool = True):
         """KLT(img0, img1, prev_kpts), the status == 1 filter and PnP on the surviving rows -- the three steps of
         ContinuousVO._process_frame (reference continuousVO.py:160-180) -- in one library call with one
         synchronisation; same results as the separate calls.
@@ -72,23 +72,26 @@ class PoseEstimation:
         :param pointcloud:  (N, 3) their landmarks, row for row
         :return (tracked_pts (N,2) float32, status (N,1) uint8, M (4,4) float64 or None when fewer than four
                  points survive or no sample gives a pose, inliers (k,1) int32 indexing the SURVIVING rows,
-                 as PnP returns them)
+                 as PnP returns them -- None with want_inliers=False, for a caller that reads self.last_inlier_mask
+                 and self.last_inlier_count instead)
         """
         a0 = np.ascontiguousarray(img0, dtype=np.uint8)
         a1 = np.ascontiguousarray(img1, dtype=np.uint8)
         if a0.ndim != 2 or a0.shape != a1.shape:
             raise ValueError("track_and_pose: img0 and img1 must be grayscale images of one size")
-        pts = np.float32(prev_kpts).reshape(-1, 2)
+        pts = np.asarray(prev_kpts, np.float32).reshape(-1, 2)
         n = pts.shape[0]
         assert pointcloud.shape[0] == n
+        self.last_inlier_count = 0
         if n == 0:
+            self.last_inlier_mask = np.zeros(0, np.uint8)
             return np.zeros((0, 2), np.float32), np.zeros((0, 1), np.uint8), None, np.zeros((0, 1), np.int32)
         ctx = _runtime.context()
         # the new frame's pyramid is built inside the call, its upload riding with the points'
         p0, p1 = _runtime.pyramids_for_pair(a0, a1, params.KLT_NUM_PYRAMIDS, params.KLT_RADIUS, reuse=reuse_pyramids,
                                             defer_next=True)
         try:
-            out, st, Rt, mask, _, good, _ = hip.track_pnp(
+            out, st, Rt, mask, _, self.last_inlier_count, _ = hip.track_pnp(
                 ctx, p0, p1, pts, pointcloud, self.K, thr=params.PNP_RANSAC_REPROJ_THRESHOLD, conf=params.PNP_RANSAC_CONFIDENCE,
                 max_iters=params.PNP_RANSAC_MAX_ITERS, refine_iters=10, klt_max_iters=params.KLT_N_ITERS, klt_eps=0.001,
                 klt_min_eig=params.KLT_MIN_EIGEN_THRESHOLD, next_image=a1)
@@ -101,7 +104,7 @@ class PoseEstimation:
             return out, st.reshape(n, 1), None, np.zeros((0, 1), np.int32)
         M = np.eye(4)
         M[0:3, :] = Rt
-        inliers = np.nonzero(mask[st == 1])[0].astype(np.int32).reshape(-1, 1)
+        inliers = np.nonzero(mask[st == 1])[0].astype(np.int32).reshape(-1, 1) if want_inliers else None
         return out, st.reshape(n, 1), M, inliers
 
     def match_key_points(self, pointcloud: np.ndarray, img0: np.ndarray, img1: np.ndarray) -> np.ndarray:
