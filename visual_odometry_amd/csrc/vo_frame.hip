@@ -19,7 +19,8 @@
 #include <new>
 #include <vector>
 
-#define FS_THREADS 256
+#define FS_THREADS 256                      // threads of a batched frame's compaction (a single frame takes FS_THREADS_ONE)
+#define FS_THREADS_ONE 1024
 #define FS_SAMPLES 256                      // samples of the first chunk
 #define FS_DRAWS (4 * FS_SAMPLES + 512)     // raw generator outputs kept on the device: room for 512 rejected draws
 #define FS_STAGE1 32                        // batched frames: samples solved and scored before the loop's bound is looked at
@@ -49,12 +50,14 @@ __device__ static inline int frame_draw_subset(const uint64_t *__restrict__ stat
 //    the next 64 subsets start four draws apart and tests its own four draws; the subsets before the first lane
 //    that met a repeated index stand, that lane's subset is drawn the long way, and the wavefront goes on behind it.
 //    With thousands of survivors a round settles 64 subsets; with a handful it settles one or two.
-// The kernel uses no LDS to speak of and four wavefronts, so that its workgroups find room on compute units that a
-// tracker launch of another stream group keeps busy.
+// Batched frames take the instance with four wavefronts (and no LDS to speak of), whose workgroups find room on
+// compute units that a tracker launch of another stream group keeps busy; a single frame has the chip to itself and
+// takes sixteen, a quarter of the compaction rounds.
 // states: the generator's state after 0, 1, ..., FS_DRAWS draws (a draw is the low half of the state after it);
 // stream b reads its own run of them, states_stride entries after stream b-1's (0: all streams draw alike).
 // starts (optional, c0 + 1 entries): how many draws precede subset i.
-__global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void frame_prep_kernel(const uint8_t *__restrict__ status, const float *__restrict__ X,
                                                                 const float *__restrict__ pts, int n,
                                                                 const uint64_t *__restrict__ states, size_t states_stride, int c0,
                                                                 float *__restrict__ Xc, float *__restrict__ xc, int *__restrict__ orig,
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
     // A kernel of the per-frame pose chain: a few short wavefronts that, with many streams in flight, share their SIMDs
     // with another launch group's tracker (five wavefronts issuing back to back).  Raised issue priority lets them through.
     __builtin_amdgcn_s_setprio(3);
-    __shared__ int wcount[2][FS_THREADS / 64];
+    __shared__ int wcount[2][THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const size_t b = blockIdx.x;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         meta = (vo_frame_meta *)((char *)meta + b * bs.out);
         counts = (int *)((char *)counts + b * bs.out);
     }
-    for (int c = tid; c <= c0; c += FS_THREADS) counts[c] = 0;
+    for (int c = tid; c <= c0; c += THREADS) counts[c] = 0;
     // The landmarks of a single frame lie in page-locked host memory (they are read once, here): a read is a trip over
     // the bus, and read inside the rounds below -- a barrier apart -- the trips of six rounds came one after the other,
     // most of this kernel's time.  The first FS_AHEAD rounds' rows are therefore asked for up front, kept or not.
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
     uint8_t ahead_status[FS_AHEAD];
 #pragma unroll
     for (int r = 0; r < FS_AHEAD; ++r) {
-        const int i = r * FS_THREADS + tid;
+        const int i = r * THREADS + tid;
         ahead_status[r] = 0;
         if (i < n) {
             ahead_status[r] = status[i];
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
         __syncthreads();          // one barrier per round: the rounds alternate between two sets of counters
         int before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < FS_THREADS / 64; ++w) {
+        for (int w = 0; w < THREADS / 64; ++w) {
             const int c = wcount[round & 1][w];
             before += w < wv ? c : 0;
             total += c;
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(FS_THREADS) void frame_prep_kernel(const uint8_t *_
     };
 #pragma unroll
     for (int r = 0; r < FS_AHEAD; ++r)
-        if (r * FS_THREADS < n) compact_round(r * FS_THREADS, r, ahead[r], ahead_status[r]);
-    for (int i0 = FS_AHEAD * FS_THREADS, round = FS_AHEAD; i0 < n; i0 += FS_THREADS, ++round) compact_round(i0, round, nullptr, 0);
+        if (r * THREADS < n) compact_round(r * THREADS, r, ahead[r], ahead_status[r]);
+    for (int i0 = FS_AHEAD * THREADS, round = FS_AHEAD; i0 < n; i0 += THREADS, ++round) compact_round(i0, round, nullptr, 0);
     if (wv != 0) return;
     const int m = base;
     if (lane == 0) {
@@ -442,7 +445,7 @@ extern "C" int vo_track_pnp(vo_ctx *ctx, const vo_pyr *prev, vo_pyr *next, const
         d_X = (const float *)(hin + o_X);
     }
     if ((rc = vo_klt_track(ctx, prev, next, d_pts, nullptr, n, klt, d_next, d_status, nullptr, VO_MEM_DEVICE))) return rc;
-    hipLaunchKernelGGL(frame_prep_kernel, dim3(1), dim3(FS_THREADS), 0, ctx->stream, d_status, d_X, d_next, n, d_raw, (size_t)0, c0, d_Xc,
+    hipLaunchKernelGGL(frame_prep_kernel<FS_THREADS_ONE>, dim3(1), dim3(FS_THREADS_ONE), 0, ctx->stream, d_status, d_X, d_next, n, d_raw, (size_t)0, c0, d_Xc,
                        d_xc, d_orig, d_meta, d_counts, d_full, d_sub, (unsigned short *)nullptr, vo_batch_strides());
     VO_HIP_CHECK(hipGetLastError());
     if (n >= 4) {
@@ -697,7 +700,7 @@ extern "C" int vo_track_pnp_batch_begin(vo_ctx *ctx, const vo_pyr *prev, const v
         VO_HIP_CHECK(hipEventRecord(ctx->prof1, ctx->stream));
         ctx->prof_recorded = true;
     }
-    hipLaunchKernelGGL(frame_prep_kernel, dim3(B), dim3(FS_THREADS), 0, ctx->stream, (const uint8_t *)d_status, d_X, (const float *)d_next, n,
+    hipLaunchKernelGGL(frame_prep_kernel<FS_THREADS>, dim3(B), dim3(FS_THREADS), 0, ctx->stream, (const uint8_t *)d_status, d_X, (const float *)d_next, n,
                        d_states, states_stride, c0, d_Xc, d_xc, d_orig, d_meta, d_counts, d_full, d_sub, d_starts, bs);
     VO_HIP_CHECK(hipGetLastError());
     // VO_FRAME_STAGE1 in the environment moves the first stage's size (0 or >= the chunk: one stage; comparison runs)
@@ -829,6 +832,7 @@ extern "C" int vo_track_pnp_batch(vo_ctx *ctx, const vo_pyr *prev, const vo_pyr 
 int vo_load_code_frame(void)
 {
     hipFuncAttributes attr;
-    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)frame_prep_kernel));
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)frame_prep_kernel<FS_THREADS>));
+    VO_HIP_CHECK(hipFuncGetAttributes(&attr, (const void *)frame_prep_kernel<FS_THREADS_ONE>));
     return VO_OK;
 }
