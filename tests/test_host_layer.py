@@ -36,6 +36,11 @@ def test_baseline_uncertainty_and_matrix_helpers_match_reference():
     assert continuousVO.baseline_uncertainty(e["T0"], e["T1"], e["landmarks"]) == pytest.approx(float(e["uncertainty"]), rel=1e-12)
     far = e["landmarks"] * np.array([1, 1, -1], np.float32) - np.array([0, 0, 100], np.float32)
     assert continuousVO.baseline_uncertainty(e["T0"], e["T1"], far) == np.inf
+    # the mask form used by the fused tracked frame: the statistic of landmarks[keep] without that array
+    keep = np.arange(e["landmarks"].shape[0]) % 3 != 0
+    assert continuousVO.baseline_uncertainty(e["T0"], e["T1"], e["landmarks"], keep) == \
+        continuousVO.baseline_uncertainty(e["T0"], e["T1"], e["landmarks"][keep])
+    assert continuousVO.baseline_uncertainty(e["T0"], e["T1"], e["landmarks"], np.zeros_like(keep)) == np.inf
     np.testing.assert_allclose(matrix.hom_inv(e["T0"]), e["T0_inv"], atol=1e-15)
     np.testing.assert_array_equal(matrix.skew(e["skew_v"]), e["skew_m"])
     np.testing.assert_array_equal(matrix.unskew(matrix.skew(e["skew_v"])).ravel(), e["skew_v"].astype(np.float32))

@@ -272,3 +272,35 @@ def test_continue_rows_equals_tracked_to_many():
         ta, tb = a.trajectory(t), b.trajectory(t)
         assert (ta.init_idx, ta.final_idx) == (tb.init_idx, tb.final_idx)
         np.testing.assert_array_equal(np.asarray(ta.pts), np.asarray(tb.pts))
+
+
+def test_landmark_store_float32_mirror_follows_every_write():
+    """float32_rows is array[ids].astype(float32) whatever path wrote the landmarks: extend (with growth), item
+    assignment, assign; the .array view refuses writes."""
+    from visual_odometry_amd.vo_pipeline.keypointTrajectory import LandmarkStore
+    rng = np.random.default_rng(2)
+    lm = LandmarkStore()
+    ids = np.array([0, 5, 99, 100, 149])
+
+    def check():
+        want = lm.array[ids].astype(np.float32)
+        got = lm.float32_rows(ids)
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, want)
+        out = np.empty((ids.size, 3), np.float32)
+        assert lm.float32_rows(ids, out=out) is out
+        np.testing.assert_array_equal(out, want)
+
+    lm.extend(rng.normal(size=(100, 3)) * 1e3)
+    lm.append(rng.normal(size=3))
+    lm.extend(rng.normal(size=(49, 3)))            # grows past the first allocation
+    assert len(lm) == 150
+    check()
+    lm[5] = [1.0, 2.0, 3.0]
+    check()
+    lm.assign(np.array([99, 149]), rng.normal(size=(2, 3)))
+    check()
+    with pytest.raises(ValueError):                # the view is read-only: a write through it would miss the mirror
+        lm.array[100] = [7.0, 8.0, 9.0]
+    lm[np.array([0, 100])] = [[7.0, 8.0, 9.0], [1.0, 1.0, 1.0]]
+    check()

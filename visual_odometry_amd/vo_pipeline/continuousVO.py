@@ -34,15 +34,16 @@ def inlier_ratio(inliers: np.ndarray, inlier_count: int) -> float:
     return inliers.shape[0] / inlier_count
 
 
-def baseline_uncertainty(T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray) -> float:
+def baseline_uncertainty(T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray, keep: Optional[np.ndarray] = None) -> float:
     """|camera-centre displacement| / mean positive landmark depth in camera 0 (continuousVO.py:249-271);
-    inf when no landmark has positive depth."""
+    inf when no landmark has positive depth.  keep (not in the reference): a boolean mask over the rows of
+    landmarks -- the depths of landmarks[keep] without building that array."""
     # the depth of X in camera 0 is the third row of its pose applied to X -- the reference's (X - C0) . (R0^T e3) with
     # the centre C0 = -R0^T t0 multiplied out --, and the centres' distance needs no full inverse either: this runs
     # on every tracked frame
     T0, T1 = np.asarray(T0, np.float64), np.asarray(T1, np.float64)
     d = landmarks @ T0[2, 0:3] + T0[2, 3]
-    d = d[d > 0]
+    d = d[d > 0] if keep is None else d[keep & (d > 0)]
     if d.size == 0:
         return np.inf
     between = T0[0:3, 0:3].T @ T0[0:3, 3] - T1[0:3, 0:3].T @ T1[0:3, 3]
@@ -267,13 +268,13 @@ class ContinuousVO:
             # the call's inlier mask is over the input rows already: no compaction of points and trajectory ids just to
             # index them again through the inlier list
             keep, n_tracked, rows = _tracked_frame_rows(status, self.poseEstimator.last_inlier_mask)
-            tracked_landmarks = prev_landmarks[keep]
+            tracked_landmarks = None        # prev_landmarks[keep], which only the depth statistic below would read
         else:
             rows = None
             tracked_pts, tracked_landmarks, trajectories = filter_tracked(status, tracked_pts, prev_landmarks,
                                                                           prev_trajectories)
             n_tracked = tracked_pts.shape[0]
-        if tracked_landmarks.shape[0] > 5:
+        if n_tracked > 5:
             if not self.fused_step:
                 T, inliers = self.poseEstimator.PnP(tracked_landmarks, tracked_pts)
             assert T is not None, "PNP RANSAC was not able to compute a pose from 2D - 3D correspondences"
@@ -298,7 +299,10 @@ class ContinuousVO:
 
         is_key = False
         prev_keyframe = self.keyframes[-2] if len(self.keyframes) >= 2 else self.keyframes[-1]
-        uncertainty = self._baseline_uncertainty(prev_keyframe.pose, T, tracked_landmarks)
+        if tracked_landmarks is None:
+            uncertainty = self._baseline_uncertainty(prev_keyframe.pose, T, prev_landmarks, keep)
+        else:
+            uncertainty = self._baseline_uncertainty(prev_keyframe.pose, T, tracked_landmarks)
         log.info("%d: tracked_pts: %5d, inlier_ratio: %.2f, baseline uncertainty: %.2f", frame_idx,
                  n_tracked, ratio, uncertainty)
         if uncertainty > params.MAX_BASELINE_UNCERTAINTY or ratio < params.MIN_INLIER_RATIO:
@@ -339,8 +343,9 @@ class ContinuousVO:
         if is_key:
             self.keyframes.append(frame_state)
 
-    def _baseline_uncertainty(self, T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray) -> float:
-        return baseline_uncertainty(T0, T1, landmarks)
+    def _baseline_uncertainty(self, T0: np.ndarray, T1: np.ndarray, landmarks: np.ndarray,
+                              keep: Optional[np.ndarray] = None) -> float:
+        return baseline_uncertainty(T0, T1, landmarks, keep)
 
     def _ba_window(self, frame_idx: int, T: np.ndarray):
         """Arrays of the BA window ending at frame_idx (continuousVO.py:273-313)."""
@@ -369,10 +374,7 @@ class ContinuousVO:
         landmark_ids = store.traj2landmark.lookup(traj_of_point)
         # the window's arrays live in buffers that are used again by the next window (they have been handed to the solver
         # and uploaded by then): a window is megabytes, and fresh arrays of that size are page faults at every keyframe
-        landmarks = workspace.take("window landmarks", landmark_ids.size, np.float32, 3)
-        gathered = workspace.take("window landmarks f64", landmark_ids.size, np.float64, 3)
-        np.take(store.landmarks.array, landmark_ids, axis=0, out=gathered)
-        landmarks[...] = gathered
+        landmarks = store.landmarks.float32_rows(landmark_ids, out=workspace.take("window landmarks", landmark_ids.size, np.float32, 3))
         return look_back, np.asarray(poses, dtype=np.float32), landmarks, ci, pi, keypoints, landmark_ids
 
     def _bundle_adjustment(self, frame_idx: int, T: np.ndarray) -> np.ndarray:
@@ -396,7 +398,7 @@ class ContinuousVO:
         hom[:, 3, 3] = 1
         for i in range(look_back):       # frames already in the queue; the current one is not yet
             self.frame_queue.get(look_back - i - 1).pose = hom[i].copy()
-        self.keypoint_trajectories.landmarks.array[landmark_ids] = adjusted_landmarks
+        self.keypoint_trajectories.landmarks.assign(landmark_ids, adjusted_landmarks)
         return hom[-1]
 
     @staticmethod

@@ -36,29 +36,47 @@ class _Growable:
 
 
 class LandmarkStore:
-    """List-like store of 3-D landmarks: append, len, [i] read and write; .array is the (n,3) view."""
+    """List-like store of 3-D landmarks: append, len, [i] read and write, assign(ids, xyz) for many at once; .array
+    is a read-only (n,3) float64 view.  The tracker and the bundle-adjustment window read landmarks as float32 at every
+    frame: a float32 mirror is kept for them (float32_rows), written by every path that writes the store -- which is
+    why .array does not allow writing."""
 
     def __init__(self):
         self._g = _Growable(3, np.float64)
+        self._m = _Growable(3, np.float32)
 
     def append(self, xyz) -> None:
-        self._g.extend(np.asarray(xyz, np.float64).reshape(1, 3))
+        self.extend(np.asarray(xyz, np.float64).reshape(1, 3))
 
     def extend(self, xyz) -> None:
-        self._g.extend(np.asarray(xyz, np.float64).reshape(-1, 3))
+        xyz = np.asarray(xyz, np.float64).reshape(-1, 3)
+        self._g.extend(xyz)
+        self._m.extend(xyz)             # converted on assignment, as .astype(np.float32) would
+
+    def assign(self, ids: np.ndarray, xyz) -> None:
+        """landmarks[ids] = xyz for many ids at once (the write-back of a bundle-adjustment window)."""
+        self._g.view[ids] = xyz
+        self._m.view[ids] = xyz
+
+    def float32_rows(self, ids: np.ndarray, out: np.ndarray = None) -> np.ndarray:
+        """array[ids].astype(np.float32), from the mirror."""
+        return np.take(self._m.view, ids, axis=0, out=out)
 
     def __len__(self) -> int:
         return self._g.n
 
     def __getitem__(self, i):
-        return self._g.view[i]
+        return self.array[i]
 
     def __setitem__(self, i, xyz) -> None:
         self._g.view[i] = xyz
+        self._m.view[i] = xyz
 
     @property
     def array(self) -> np.ndarray:
-        return self._g.view
+        view = self._g.view
+        view.flags.writeable = False
+        return view
 
 
 class _TrajToLandmark:
@@ -261,7 +279,7 @@ class KeypointTrajectories:
             obs.served = (self.traj2landmark.version, pts, kept, lid)
         if not with_landmarks:
             return pts, kept, None
-        return pts, kept, self.landmarks.array[lid].astype(np.float32).reshape(-1, 3)
+        return pts, kept, self.landmarks.float32_rows(lid).reshape(-1, 3)
 
     def trajectory(self, traj_idx: int) -> Trajectory:
         """Per-trajectory record; the point of a skipped frame repeats the next registered one."""
@@ -290,13 +308,13 @@ class KeypointTrajectories:
 
     def get_active(self) -> List[np.ndarray]:
         _, lid = self._latest()
-        return list(self.landmarks.array[lid[lid >= 0]])
+        return list(self.landmarks._g.view[lid[lid >= 0]])
 
     def get_all(self) -> List[np.ndarray]:
         ids, lid = self._latest()
         if np.any(lid < 0):
             raise KeyError(int(ids[lid < 0][0]))
-        return list(self.landmarks.array[lid])
+        return list(self.landmarks._g.view[lid])
 
     def get_inactive(self) -> List[np.ndarray]:
         return []   # trajectories without a landmark have none to return
