@@ -48,6 +48,23 @@ def test_pyramid_bit_exact(oracle, ctx, shape):
             np.testing.assert_array_equal(pyr.download(b, l), oracle.pyr_level(imgs[b], l))
 
 
+@pytest.mark.parametrize("batch,shape,max_level", [(1, (480, 640), 8), (1, (480, 640), 3), (2, (479, 637), 8), (4, (720, 1280), 8),
+                                                   (1, (1080, 1920), 8), (1, (188, 621), 2), (1, (100, 130), 8), (5, (480, 640), 8)])
+def test_pyramid_small_levels_in_one_launch(oracle, ctx, batch, shape, max_level):
+    """The last two to four levels of up to four images are built by one launch (tiles of the last level, the levels
+    in between recomputed per tile): every level bit-exact against pyrDown, for two, three and four such levels, odd
+    sizes, a source level that is the caller's image (byte reads) or the pyramid's own (dword reads), host images;
+    five images take the launch-per-level path and must agree just the same."""
+    from visual_odometry_amd import hip
+    rng = np.random.default_rng(batch * 1000 + shape[0])
+    imgs = rng.integers(0, 256, (batch,) + shape, dtype=np.uint8)
+    pyr = hip.Pyramid(ctx, batch, shape[0], shape[1], max_level).build(imgs if batch > 1 else imgs[0])
+    assert pyr.max_level == oracle.pyr_max_level(shape[1], shape[0], max_level)
+    for b in range(batch):
+        for l in range(pyr.max_level + 1):
+            np.testing.assert_array_equal(pyr.download(b, l), oracle.pyr_level(imgs[b], l))
+
+
 @pytest.mark.parametrize("batch,shape", [(8, (50, 91)), (16, (44, 45)), (8, (376, 1241)), (5, (45, 44)), (1, (23, 300))])
 def test_pyramid_batches_and_strides(oracle, ctx, batch, shape):
     """Batches that take the image-per-XCD workgroup order (multiples of 8) and those that do not, the narrowest

@@ -216,6 +216,159 @@ static int pyr_own_level0(vo_ctx *ctx, vo_pyr *pyr);
 static int pyr_launch_levels(vo_ctx *ctx, vo_pyr *pyr);
 #define PYR_STAGED_MAX_BYTES ((size_t)1 << 20)     // host images up to this size go through vo_upload's page-locked ring
 
+// ---- the small levels of a few images in one launch ------------------------------------------------------------
+// A level of a single 640x480 frame is a launch at its floor (3-4 us for 20-80 thousand pixels), and a level waits
+// for the one before it: three such levels were 12 us of a tracked frame's 140.  Here the last PT_LEVELS_MAX or fewer
+// levels are built by one launch without any exchange between workgroups: a workgroup owns a PT_TILE x PT_TILE tile of
+// the LAST level, brings the part of the source level that tile depends on into LDS (2r + 3 pixels a side per level,
+// r the side one level up: 19, 41, 85 for three levels), and computes level after level from LDS into LDS, borders
+// reflected on the levels' own coordinates.  A pixel of an intermediate level is written to memory by the one
+// workgroup whose tile it lies under (x >> s, y >> s with s the levels in between); what neighbours need of it they
+// compute again themselves (1.6 times the pixels on the largest level).  Same arithmetic as pyr_down_rows_kernel.
+#define PT_TILE 4
+#define PT_LEVELS_MAX 4
+#define PT_THREADS 256
+struct PyrTailArgs {
+    const uint8_t *src;             // the level the first built level is formed from
+    int sw, sh;
+    int64_t spitch, sstride;        // bytes between its rows / images
+    int levels;                     // levels built
+    int src_dwords;                 // the source's rows start on 4-byte boundaries and may be read up to their pitch
+    uint8_t *dst[PT_LEVELS_MAX];
+    int w[PT_LEVELS_MAX], h[PT_LEVELS_MAX];
+    int64_t pitch[PT_LEVELS_MAX], stride[PT_LEVELS_MAX];
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int pt_reflect(int i, int n)         // REFLECT_101, |overshoot| < n
+{
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void pyr_tail_kernel(PyrTailArgs a)
+{
+    extern __shared__ uint8_t pt_lds[];
+    const int tile = blockIdx.x % (a.tiles_x * a.tiles_y), image = blockIdx.x / (a.tiles_x * a.tiles_y);
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int last = a.levels - 1;
+    // the rectangle of every level this tile depends on, clipped to the level: lo[k] .. hi[k] (k = -1: the source)
+    int xlo[PT_LEVELS_MAX + 1], xhi[PT_LEVELS_MAX + 1], ylo[PT_LEVELS_MAX + 1], yhi[PT_LEVELS_MAX + 1];
+    xlo[last + 1] = tx * PT_TILE; xhi[last + 1] = min(a.w[last], (tx + 1) * PT_TILE) - 1;
+    ylo[last + 1] = ty * PT_TILE; yhi[last + 1] = min(a.h[last], (ty + 1) * PT_TILE) - 1;
+#pragma unroll
+    for (int k = PT_LEVELS_MAX - 1; k >= 0; --k) {
+        if (k > last) continue;
+        const int wk = k == 0 ? a.sw : a.w[k - 1], hk = k == 0 ? a.sh : a.h[k - 1];     // the level below level k's output
+        xlo[k] = max(0, 2 * xlo[k + 1] - 2); xhi[k] = min(wk - 1, 2 * xhi[k + 1] + 2);
+        ylo[k] = max(0, 2 * ylo[k + 1] - 2); yhi[k] = min(hk - 1, 2 * yhi[k + 1] + 2);
+    }
+    // two LDS areas used in turn; the source rectangle is the largest
+    const int side0 = ((PT_TILE + 3) << PT_LEVELS_MAX) - 3;
+    uint8_t *cur = pt_lds, *nxt = pt_lds + (side0 + 8) * side0;               // rows of the source rounded out to dwords
+    // The source rectangle was written by the launch before this one, on other XCDs: every read is a trip to memory,
+    // and a thread's reads must all be in flight together.  Rows of a library-owned level start on 64-byte
+    // boundaries: the rectangle comes in as whole dwords (eight or so per thread instead of twenty-eight bytes), its
+    // left edge moved down to a multiple of four.  A caller's level 0 (any pitch) is read byte by byte.
+    const int x_origin = a.src_dwords ? (xlo[0] & ~3) : xlo[0];
+    const int src_row = a.src_dwords ? ((xhi[0] - x_origin) / 4 + 1) * 4 : xhi[0] - xlo[0] + 1;      // bytes per row in LDS
+    {
+        const int rh = yhi[0] - ylo[0] + 1;
+        const uint8_t *g = a.src + image * a.sstride;
+        if (a.src_dwords) {
+            const int rd = src_row / 4, n = rd * rh;
+            for (int i0 = threadIdx.x; i0 < n; i0 += 16 * PT_THREADS) {
+                uint32_t v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + u * PT_THREADS;
+                    const int y = i / rd, x = i - y * rd;
+                    v[u] = i < n ? *(const uint32_t *)(g + (int64_t)(ylo[0] + y) * a.spitch + x_origin + 4 * x) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + u * PT_THREADS;
+                    if (i < n) ((uint32_t *)cur)[i] = v[u];
+                }
+            }
+        } else {
+            const int n = src_row * rh;
+            for (int i0 = threadIdx.x; i0 < n; i0 += 16 * PT_THREADS) {
+                uint8_t v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + u * PT_THREADS;
+                    const int y = i / src_row, x = i - y * src_row;
+                    v[u] = i < n ? g[(int64_t)(ylo[0] + y) * a.spitch + x_origin + x] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + u * PT_THREADS;
+                    if (i < n) cur[i] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PT_LEVELS_MAX; ++k) {
+        if (k > last) break;
+        const int sw = k == 0 ? a.sw : a.w[k - 1], sh = k == 0 ? a.sh : a.h[k - 1];
+        const int srw = k == 0 ? src_row : xhi[k] - xlo[k] + 1;                 // row length of the rectangle in `cur`
+        const int sx0 = k == 0 ? x_origin : xlo[k];                             // its first column
+        const int rw = xhi[k + 1] - xlo[k + 1] + 1, rh = yhi[k + 1] - ylo[k + 1] + 1;
+        const int shift = last - k;
+        uint8_t *g = a.dst[k] + image * a.stride[k];
+        for (int i = threadIdx.x; i < rw * rh; i += PT_THREADS) {
+            const int ry = i / rw, rx = i - ry * rw;
+            const int x = xlo[k + 1] + rx, y = ylo[k + 1] + ry;
+            int cx[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) cx[t] = pt_reflect(2 * x - 2 + t, sw) - sx0;
+            int v = 0;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const uint8_t *row = cur + (pt_reflect(2 * y - 2 + r, sh) - ylo[k]) * srw;
+                const int hsum = row[cx[2]] * 6 + (row[cx[1]] + row[cx[3]]) * 4 + row[cx[0]] + row[cx[4]];
+                v += hsum * (r == 2 ? 6 : (r == 1 || r == 3) ? 4 : 1);
+            }
+            const uint8_t out = (uint8_t)((v + 128) >> 8);
+            nxt[i] = out;
+            if ((x >> shift) / PT_TILE == tx && (y >> shift) / PT_TILE == ty) g[(int64_t)y * a.pitch[k] + x] = out;
+        }
+        __syncthreads();
+        uint8_t *t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// Levels first .. max_level by pyr_tail_kernel, when that pays: a handful of images whose level `first` is small.
+static bool pyr_tail_applies(const vo_pyr *pyr, int first)
+{
+    const int levels = pyr->max_level - first + 1;
+    return levels >= 2 && levels <= PT_LEVELS_MAX && pyr->batch <= 4 && (int64_t)pyr->w[first] * pyr->h[first] <= 65536;
+}
+
+static int pyr_launch_tail(vo_ctx *ctx, vo_pyr *pyr, int first)
+{
+    PyrTailArgs a;
+    a.src = pyr->lvl[first - 1]; a.sw = pyr->w[first - 1]; a.sh = pyr->h[first - 1];
+    a.spitch = pyr->pitch[first - 1]; a.sstride = pyr->img_stride[first - 1];
+    a.levels = pyr->max_level - first + 1;
+    a.src_dwords = first >= 2;      // a level of the pyramid's own pool (pitch a multiple of 64); level 0 may be the caller's
+    for (int k = 0; k < PT_LEVELS_MAX; ++k) {
+        const int l = first + (k < a.levels ? k : a.levels - 1);
+        a.dst[k] = pyr->lvl[l]; a.w[k] = pyr->w[l]; a.h[k] = pyr->h[l]; a.pitch[k] = pyr->pitch[l]; a.stride[k] = pyr->img_stride[l];
+    }
+    a.tiles_x = (a.w[a.levels - 1] + PT_TILE - 1) / PT_TILE;
+    a.tiles_y = (a.h[a.levels - 1] + PT_TILE - 1) / PT_TILE;
+    const int side0 = ((PT_TILE + 3) << PT_LEVELS_MAX) - 3, side1 = ((PT_TILE + 3) << (PT_LEVELS_MAX - 1)) - 3;
+    const size_t lds = (size_t)(side0 + 8) * side0 + (size_t)side1 * side1;
+    static_assert((size_t)(((PT_TILE + 3) << PT_LEVELS_MAX) - 3) * (((PT_TILE + 3) << PT_LEVELS_MAX) - 3) * 5 / 4 < 64 * 1024,
+                  "the two areas fit the LDS a launch gets by default");
+    hipLaunchKernelGGL(pyr_tail_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * pyr->batch)), dim3(PT_THREADS), lds, ctx->stream, a);
+    return VO_OK;
+}
+
 extern "C" int vo_pyr_build(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t row_stride, int64_t img_stride, int mem)
 {
     VO_REQUIRE(ctx && pyr && img, "vo_pyr_build: NULL argument");
@@ -296,6 +449,11 @@ int vo_pyr_build_pinned(vo_ctx *ctx, vo_pyr *pyr, const uint8_t *img, int64_t ro
 static int pyr_launch_levels(vo_ctx *ctx, vo_pyr *pyr)
 {
     for (int l = 1; l <= pyr->max_level; ++l) {
+        if (pyr_tail_applies(pyr, l)) {
+            int rc = pyr_launch_tail(ctx, pyr, l);
+            if (rc) return rc;
+            break;
+        }
         const int groups = (pyr->w[l] + 3) / 4;
         // eight output rows per lane unless that leaves fewer than ~2 wavefronts per SIMD
         const bool tall = (int64_t)groups * ((pyr->h[l] + 7) / 8) * pyr->batch >= PR_TALL_MIN_LANES;
